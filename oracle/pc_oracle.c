@@ -1,0 +1,407 @@
+/* pc_oracle.c -- CPU oracle for the ProgressiveCodec encode/decode hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under progressivecodec_amd/ links, loads or
+ * calls this file; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do, and only as the checker.
+ *
+ * Two kinds of functions live here:
+ *  (1) integer / byte stages restated from the reference, bit-exact by
+ *      construction and pinned by tests/golden (rANS coder, pmf->CDF, scale->index,
+ *      quantile mask, quantise);
+ *  (2) the float32 network primitives evaluated in the *defined summation order*
+ *      of the bitstream contract (DESIGN.md "numeric contract"): every output
+ *      element is one fmaf chain over (tap, input-channel) ascending, starting at
+ *      +0, bias added afterwards; transcendental functions from include/pc_math.h.
+ *      The HIP kernels implement the same chains on the f32 MFMA pipe, so GPU and
+ *      oracle agree bit-for-bit.  Against the PyTorch reference these agree to
+ *      float rounding (tests/test_oracle_vs_golden.py); PyTorch's own oneDNN order
+ *      is not reproducible across machines or thread counts.
+ *
+ * Each function cites the reference file:line it follows (paths relative to
+ * /root/reference/src).
+ */
+#include <immintrin.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#include "../include/pc_math.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------------- */
+/* rANS (ryg rans64, 16-bit precision, 4-bit bypass)                          */
+/* ------------------------------------------------------------------------- */
+
+#define RANS_L (1ull << 31)           /* third_party/ryg_rans/rans64.h:59 */
+#define PRECISION 16                  /* compress/cpp_exts/rans/rans_interface.cpp:40 */
+#define BYPASS_BITS 4                 /* rans_interface.cpp:42 */
+#define BYPASS_MAX 15                 /* rans_interface.cpp:43 */
+
+typedef struct { uint16_t start, range; uint8_t bypass; } orc_sym_t;
+
+/* rans_interface.cpp:99-164 (symbol -> (start, range) records, with the escape
+ * through bypass nibbles) followed by :166-191 (flush: encode records in reverse,
+ * 32-bit words written backwards, final 64-bit state as two words).
+ * Returns 0, or -1 bad index, -2 out buffer too small, -3 allocation. */
+ORC_API int orc_rans_encode(const int32_t *sym, const int32_t *idx, int64_t n,
+                            const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                            const int32_t *offset, int n_cdf,
+                            uint8_t *out, int64_t cap, int64_t *out_len)
+{
+    int64_t cap_rec = n + 16, n_rec = 0;
+    orc_sym_t *rec = (orc_sym_t *)malloc(sizeof(orc_sym_t) * (size_t)cap_rec);
+    if (!rec) return -3;
+#define PUSH(S, R, B) do { if (n_rec == cap_rec) { cap_rec = cap_rec * 2; \
+        rec = (orc_sym_t *)realloc(rec, sizeof(orc_sym_t) * (size_t)cap_rec); if (!rec) return -3; } \
+        rec[n_rec].start = (uint16_t)(S); rec[n_rec].range = (uint16_t)(R); rec[n_rec].bypass = (B); n_rec++; } while (0)
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = idx[i];
+        if (ci < 0 || ci >= n_cdf) { free(rec); return -1; }
+        const int32_t *c = cdf + (int64_t)ci * cdf_stride;
+        const int32_t max_value = cdf_len[ci] - 2;               /* :115 */
+        int32_t value = sym[i] - offset[ci];                     /* :119 */
+        uint32_t raw = 0;
+        if (value < 0) { raw = (uint32_t)(-2 * value - 1); value = max_value; }          /* :122-124 */
+        else if (value >= max_value) { raw = (uint32_t)(2 * (value - max_value)); value = max_value; } /* :125-128 */
+        PUSH(c[value], c[value + 1] - c[value], 0);              /* :133-135 */
+        if (value == max_value) {                                /* :138-162 */
+            int32_t n_bypass = 0;
+            while ((raw >> (n_bypass * BYPASS_BITS)) != 0) ++n_bypass;
+            int32_t val = n_bypass;
+            while (val >= BYPASS_MAX) { PUSH(BYPASS_MAX, BYPASS_MAX + 1, 1); val -= BYPASS_MAX; }
+            PUSH(val, val + 1, 1);
+            for (int32_t j = 0; j < n_bypass; ++j) {
+                const int32_t v = (int32_t)((raw >> (j * BYPASS_BITS)) & BYPASS_MAX);
+                PUSH(v, v + 1, 1);
+            }
+        }
+    }
+#undef PUSH
+    /* flush(): rans_interface.cpp:166-191; Rans64EncPut rans64.h:77-93; EncPutBits cpp:60-78 */
+    int64_t nw_cap = n_rec + 2;
+    uint32_t *buf = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)nw_cap);
+    if (!buf) { free(rec); return -3; }
+    uint32_t *ptr = buf + nw_cap;
+    uint64_t x = RANS_L;
+    for (int64_t k = n_rec - 1; k >= 0; --k) {
+        const uint32_t start = rec[k].start;
+        if (!rec[k].bypass) {
+            const uint32_t freq = rec[k].range;
+            const uint64_t x_max = ((RANS_L >> PRECISION) << 32) * freq;
+            if (x >= x_max) { *--ptr = (uint32_t)x; x >>= 32; }
+            x = ((x / freq) << PRECISION) + (x % freq) + start;
+        } else {
+            const uint32_t freq = 1u << (16 - BYPASS_BITS);
+            const uint64_t x_max = ((RANS_L >> 16) << 32) * freq;
+            if (x >= x_max) { *--ptr = (uint32_t)x; x >>= 32; }
+            x = (x << BYPASS_BITS) | start;
+        }
+    }
+    ptr -= 2;                                                    /* Rans64EncFlush rans64.h:96-103 */
+    ptr[0] = (uint32_t)x; ptr[1] = (uint32_t)(x >> 32);
+    const int64_t nbytes = (int64_t)((buf + nw_cap) - ptr) * 4;
+    int rc = 0;
+    if (nbytes > cap) rc = -2; else memcpy(out, ptr, (size_t)nbytes);
+    *out_len = nbytes;
+    free(buf); free(rec);
+    return rc;
+}
+
+/* rans_interface.cpp:206-275; Rans64DecInit/Get/Advance rans64.h:107-142; DecGetBits cpp:80-96.
+ * Returns 0, -1 bad index, -4 truncated stream. */
+ORC_API int orc_rans_decode(const uint8_t *in, int64_t in_len, const int32_t *idx, int64_t n,
+                            const int32_t *cdf, int cdf_stride, const int32_t *cdf_len,
+                            const int32_t *offset, int n_cdf, int32_t *out)
+{
+    if (in_len < 8) return -4;
+    const int64_t nw = in_len / 4;
+    int64_t p = 2;
+    uint32_t w0, w1; memcpy(&w0, in, 4); memcpy(&w1, in + 4, 4);
+    uint64_t x = (uint64_t)w0 | ((uint64_t)w1 << 32);
+#define NEXTWORD(dst) do { if (p >= nw) return -4; uint32_t _w; memcpy(&_w, in + 4 * p, 4); ++p; dst = _w; } while (0)
+#define GETBITS(dst) do { dst = (int32_t)(x & ((1u << BYPASS_BITS) - 1)); x >>= BYPASS_BITS; \
+        if (x < RANS_L) { uint32_t _v; NEXTWORD(_v); x = (x << 32) | _v; } } while (0)
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t ci = idx[i];
+        if (ci < 0 || ci >= n_cdf) return -1;
+        const int32_t *c = cdf + (int64_t)ci * cdf_stride;
+        const int32_t len = cdf_len[ci];
+        const int32_t max_value = len - 2;
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+        int32_t k = 0;                       /* first k with c[k] > cf (std::find_if, :238) */
+        while (k < len && (uint32_t)c[k] <= cf) ++k;
+        const int32_t s = k - 1;
+        const uint32_t start = (uint32_t)c[s], freq = (uint32_t)(c[s + 1] - c[s]);
+        x = (uint64_t)freq * (x >> PRECISION) + (x & 0xFFFFu) - start;
+        if (x < RANS_L) { uint32_t v; NEXTWORD(v); x = (x << 32) | v; }
+        int32_t value = s;
+        if (value == max_value) {            /* :247-269 */
+            int32_t val; GETBITS(val);
+            int32_t n_bypass = val;
+            while (val == BYPASS_MAX) { GETBITS(val); n_bypass += val; }
+            int32_t raw = 0;
+            for (int32_t j = 0; j < n_bypass; ++j) { GETBITS(val); raw |= val << (j * BYPASS_BITS); }
+            value = raw >> 1;
+            if (raw & 1) value = -value - 1; else value += max_value;
+        }
+        out[i] = value + offset[ci];
+    }
+#undef GETBITS
+#undef NEXTWORD
+    return 0;
+}
+
+/* compress/cpp_exts/ops/ops.cpp:10-67.  cdf has n+1 entries.  Returns 0 or -1 (no stealable bin). */
+ORC_API int orc_pmf_to_quantized_cdf(const float *pmf, int n, int precision, uint32_t *cdf)
+{
+    cdf[0] = 0;
+    for (int i = 0; i < n; ++i) cdf[i + 1] = (uint32_t)roundf(pmf[i] * (float)(1 << precision)); /* :20-21 */
+    uint32_t total = 0;
+    for (int i = 0; i <= n; ++i) total += cdf[i];                                               /* :23 */
+    if (total == 0) return -1;
+    for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)((((uint64_t)1 << precision) * cdf[i]) / total); /* :25-28 */
+    for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];                                          /* :30 */
+    cdf[n] = 1u << precision;                                                                   /* :31 */
+    for (int i = 0; i < n; ++i) {                                                               /* :33-58 */
+        if (cdf[i] == cdf[i + 1]) {
+            uint32_t best_freq = ~0u; int best = -1;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t f = cdf[j + 1] - cdf[j];
+                if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+            }
+            if (best < 0) return -1;
+            if (best < i) { for (int j = best + 1; j <= i; ++j) cdf[j]--; }
+            else { for (int j = i + 1; j <= best; ++j) cdf[j]++; }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* index / mask / quantise                                                    */
+/* ------------------------------------------------------------------------- */
+
+/* GaussianConditional.build_indexes, entropy_models.py:661-666 (LowerBound = max, bound_ops.py:21-22):
+ * idx = (nt-1) - #{k < nt-1 : max(scale, bound) <= table[k]}. */
+ORC_API void orc_build_indexes(const float *scale, int64_t n, const float *table, int nt, float bound, int32_t *idx)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float s = scale[i];
+        s = (s != s) ? s : (s > bound ? s : bound);        /* torch.max propagates NaN */
+        int32_t v = nt - 1;
+        for (int k = 0; k < nt - 1; ++k) v -= (s <= table[k]) ? 1 : 0;
+        idx[i] = v;
+    }
+}
+
+static int cmp_float(const void *a, const void *b)
+{
+    const float x = *(const float *)a, y = *(const float *)b;
+    return (x > y) - (x < y);
+}
+
+/* torch.quantile(v, q) with the default 'linear' interpolation as ATen evaluates it
+ * for a float32 tensor: rank = q * (n - 1) in float32, lerp between the two order
+ * statistics with ATen's lerp formula (fused as noted below; pinned by
+ * tests/golden/quantile_cases.npz, generated from torch.quantile itself). */
+ORC_API float orc_quantile(const float *v, int64_t n, float q)
+{
+    float *s = (float *)malloc(sizeof(float) * (size_t)n);
+    memcpy(s, v, sizeof(float) * (size_t)n);
+    for (int64_t i = 0; i < n; ++i) if (s[i] != s[i]) { free(s); return NAN; }
+    qsort(s, (size_t)n, sizeof(float), cmp_float);
+    const float rank = q * (float)(n - 1);
+    const float lo_f = floorf(rank), hi_f = ceilf(rank);
+    const float w = rank - lo_f;
+    const float a = s[(int64_t)lo_f], b = s[(int64_t)hi_f];
+    const float d = b - a;
+    /* ATen's CPU lerp evaluates both branches with a fused multiply-add (its AVX2/AVX-512
+     * kernels are built with FMA contraction): 2420/2420 cases match torch.quantile with
+     * fmaf, 102 of them differ by one ulp without it. */
+    const float r = (fabsf(w) < 0.5f) ? fmaf(w, d, a) : fmaf(-d, 1.0f - w, b);
+    free(s);
+    return r;
+}
+
+/* ChannelMask.forward, policy "point-based-std": layers/masking.py:205-223.
+ * scale is [B][n_per] (one image = one contiguous block, any element order);
+ * pr is the call-time `quality`.  mask out as float 0/1. */
+ORC_API void orc_mask_point_based_std(const float *scale, int B, int64_t n_per, double pr, float *mask, float *thr_out)
+{
+    if (pr >= 10.0) { for (int64_t i = 0; i < B * n_per; ++i) mask[i] = 1.0f; return; }  /* :206-207 */
+    if (pr == 0.0) { for (int64_t i = 0; i < B * n_per; ++i) mask[i] = 0.0f; return; }   /* :208-209 */
+    const double prf = pr * 0.1;                         /* :212 (python float arithmetic) */
+    const double q = 1.0 - prf;                          /* :213 */
+    for (int b = 0; b < B; ++b) {
+        const float *s = scale + (int64_t)b * n_per;
+        const float thr = orc_quantile(s, n_per, (float)q);   /* :218 */
+        if (thr_out) thr_out[b] = thr;
+        for (int64_t i = 0; i < n_per; ++i) mask[(int64_t)b * n_per + i] = (s[i] >= thr) ? 1.0f : 0.0f; /* :219 */
+    }
+}
+
+/* EntropyModel.quantize(..., "symbols", means): entropy_models.py:137-150
+ * (x - mu, torch.round = half to even, .int()). mu may be NULL. */
+ORC_API void orc_quantize(const float *x, const float *mu, int64_t n, int32_t *sym)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const float d = mu ? x[i] - mu[i] : x[i];
+        sym[i] = (int32_t)pc_roundevenf(d);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* float32 primitives in the contract's summation order                       */
+/* ------------------------------------------------------------------------- */
+
+/* elementwise functions of pc_math.h over an array */
+ORC_API void orc_unary(float *x, int64_t n, int op)
+{
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < n; ++i) {
+        const float v = x[i];
+        float r;
+        switch (op) {
+        case 0: r = pc_geluf(v); break;
+        case 1: r = pc_tanhf(v); break;
+        case 2: r = pc_sigmoidf(v); break;
+        case 3: r = pc_rsqrtf(v); break;
+        case 4: r = sqrtf(v); break;
+        case 5: r = pc_expf(v); break;
+        case 6: r = pc_erff(v); break;
+        default: r = v;
+        }
+        x[i] = r;
+    }
+}
+
+/* Generic "tap list" convolution over NHWC activations:
+ *   out[b, i*osy+ooy, j*osx+oox, n] = sum_{t<T} sum_{c<Cin} f(x[b, i*stride+dy[t], j*stride+dx[t], c]) * w[t][c][n]
+ * evaluated per output element as ONE fmaf chain in (t, c) ascending order from +0
+ * (taps falling outside the image contribute a = 0, which leaves the chain's value
+ * unchanged).  f = identity, or x*x when square != 0 (GDN: F.conv2d(x**2, gamma), gdn.py:56).
+ * Covers nn.Conv2d 5x5 s2 / 3x3 s1,s2 / 1x1 (models/utils.py:186, layers.py:15,27), nn.Linear
+ * (1 tap) and each output phase of ConvTranspose2d(5, s2, p2, op1) (models/utils.py:196).
+ * No bias: the caller adds it afterwards (one float add), as the contract says. */
+ORC_API void orc_conv_nhwc(const float *x, int B, int H, int W, int Cin, int ldx,
+                           const float *w, const int *dy, const int *dx, int T, int stride,
+                           int Ho, int Wo, int Cout,
+                           float *out, int outH, int outW, int osy, int ooy, int osx, int oox, int ldo,
+                           int square)
+{
+    float *zeros = (float *)calloc((size_t)Cin, sizeof(float));
+    const int64_t rows = (int64_t)B * Ho;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t r = 0; r < rows; ++r) {
+        const int b = (int)(r / Ho), i = (int)(r % Ho);
+        const float *xp[4][32];
+        for (int j0 = 0; j0 < Wo; j0 += 4) {
+            const int P = (Wo - j0) < 4 ? (Wo - j0) : 4;
+            for (int t = 0; t < T; ++t)
+                for (int p = 0; p < 4; ++p) {
+                    const int iy = i * stride + dy[t], ix = (j0 + (p < P ? p : 0)) * stride + dx[t];
+                    xp[p][t] = (p < P && iy >= 0 && iy < H && ix >= 0 && ix < W)
+                                   ? x + (((int64_t)b * H + iy) * W + ix) * ldx : zeros;
+                }
+            float *op[4];
+            for (int p = 0; p < 4; ++p) {
+                const int jj = j0 + (p < P ? p : 0);
+                op[p] = out + (((int64_t)b * outH + (i * osy + ooy)) * outW + (jj * osx + oox)) * ldo;
+            }
+            int n0 = 0;
+            for (; n0 + 16 <= Cout; n0 += 16) {
+                __m256 a00 = _mm256_setzero_ps(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00, a30 = a00, a31 = a00;
+                for (int t = 0; t < T; ++t) {
+                    const float *wt = w + ((int64_t)t * Cin) * Cout + n0;
+                    const float *x0 = xp[0][t], *x1 = xp[1][t], *x2 = xp[2][t], *x3 = xp[3][t];
+                    for (int c = 0; c < Cin; ++c) {
+                        const __m256 w0 = _mm256_loadu_ps(wt + (int64_t)c * Cout), w1 = _mm256_loadu_ps(wt + (int64_t)c * Cout + 8);
+                        float v0 = x0[c], v1 = x1[c], v2 = x2[c], v3 = x3[c];
+                        if (square) { v0 *= v0; v1 *= v1; v2 *= v2; v3 *= v3; }
+                        const __m256 b0 = _mm256_set1_ps(v0), b1 = _mm256_set1_ps(v1), b2 = _mm256_set1_ps(v2), b3 = _mm256_set1_ps(v3);
+                        a00 = _mm256_fmadd_ps(b0, w0, a00); a01 = _mm256_fmadd_ps(b0, w1, a01);
+                        a10 = _mm256_fmadd_ps(b1, w0, a10); a11 = _mm256_fmadd_ps(b1, w1, a11);
+                        a20 = _mm256_fmadd_ps(b2, w0, a20); a21 = _mm256_fmadd_ps(b2, w1, a21);
+                        a30 = _mm256_fmadd_ps(b3, w0, a30); a31 = _mm256_fmadd_ps(b3, w1, a31);
+                    }
+                }
+                _mm256_storeu_ps(op[0] + n0, a00); _mm256_storeu_ps(op[0] + n0 + 8, a01);
+                if (P > 1) { _mm256_storeu_ps(op[1] + n0, a10); _mm256_storeu_ps(op[1] + n0 + 8, a11); }
+                if (P > 2) { _mm256_storeu_ps(op[2] + n0, a20); _mm256_storeu_ps(op[2] + n0 + 8, a21); }
+                if (P > 3) { _mm256_storeu_ps(op[3] + n0, a30); _mm256_storeu_ps(op[3] + n0 + 8, a31); }
+            }
+            for (; n0 < Cout; ++n0) {        /* scalar tail (Cout = 3, or Cout % 16) */
+                for (int p = 0; p < P; ++p) {
+                    float acc = 0.0f;
+                    for (int t = 0; t < T; ++t) {
+                        const float *wt = w + ((int64_t)t * Cin) * Cout + n0;
+                        const float *xx = xp[p][t];
+                        for (int c = 0; c < Cin; ++c) {
+                            float v = xx[c];
+                            if (square) v *= v;
+                            acc = fmaf(v, wt[(int64_t)c * Cout], acc);
+                        }
+                    }
+                    op[p][n0] = acc;
+                }
+            }
+        }
+    }
+    free(zeros);
+}
+
+/* Shifted-window multi-head self-attention core (between the qkv and proj Linears):
+ * WinBasedAttention.forward win_attention.py:153-207 + WindowAttention.forward :84-115.
+ * qkv: [B][H][W][3C] (channel = which*C + head*d + e, the reshape at :91);
+ * bias: dense [heads][T][T] gathered from relative_position_bias_table (:97-100);
+ * out:  [B][H][W][C], written at the *unshifted* pixel of each query token
+ * (roll(-s) :180, partition :185, reverse :193, roll(+s) :197 are index maps only).
+ * Per (window, head, query i): s_j = fmaf-chain_e (q_i[e]*scale)*k_j[e]; s_j += bias; s_j += mask(0/-100)
+ * (:164-175, only when shift > 0); p = exp(s - max) / sum (sum in ascending j); o[e] = fmaf-chain_j p_j*v_j[e]. */
+ORC_API void orc_win_attention(const float *qkv, const float *bias, int B, int H, int W, int C,
+                               int heads, int ws, int shift, float scale, float *out)
+{
+    const int T = ws * ws, d = C / heads, nwy = H / ws, nwx = W / ws;
+    const int64_t nwin = (int64_t)B * nwy * nwx;
+#pragma omp parallel for schedule(static)
+    for (int64_t wi = 0; wi < nwin; ++wi) {
+        const int b = (int)(wi / (nwy * nwx)), wy = (int)((wi / nwx) % nwy), wx = (int)(wi % nwx);
+        int64_t pix[64]; int reg[64];
+        for (int t = 0; t < T; ++t) {
+            const int ys = wy * ws + t / ws, xs = wx * ws + t % ws;       /* shifted-frame coords */
+            const int y = (ys + shift) % H, xx = (xs + shift) % W;        /* roll(-shift): shifted[y] = x[y+shift] */
+            pix[t] = ((int64_t)b * H + y) * W + xx;
+            const int ry = ys < H - ws ? 0 : (ys < H - shift ? 1 : 2);    /* :159-164 region ids */
+            const int rx = xs < W - ws ? 0 : (xs < W - shift ? 1 : 2);
+            reg[t] = ry * 3 + rx;
+        }
+        float s[64], qs[128];
+        for (int h = 0; h < heads; ++h) {
+            for (int i = 0; i < T; ++i) {
+                const float *q = qkv + pix[i] * 3 * C + h * d;
+                for (int e = 0; e < d; ++e) qs[e] = q[e] * scale;         /* :94 */
+                float m = -INFINITY;
+                for (int j = 0; j < T; ++j) {
+                    const float *k = qkv + pix[j] * 3 * C + C + h * d;
+                    float acc = 0.0f;
+                    for (int e = 0; e < d; ++e) acc = fmaf(qs[e], k[e], acc);
+                    acc = acc + bias[((int64_t)h * T + i) * T + j];
+                    if (shift > 0) acc = acc + (reg[i] != reg[j] ? -100.0f : 0.0f);
+                    s[j] = acc;
+                    m = acc > m ? acc : m;
+                }
+                float sum = 0.0f;
+                for (int j = 0; j < T; ++j) { s[j] = pc_expf(s[j] - m); sum = sum + s[j]; }
+                for (int j = 0; j < T; ++j) s[j] = s[j] / sum;
+                float *o = out + pix[i] * C + h * d;
+                for (int e = 0; e < d; ++e) {
+                    float acc = 0.0f;
+                    for (int j = 0; j < T; ++j) acc = fmaf(s[j], qkv[pix[j] * 3 * C + 2 * C + h * d + e], acc);
+                    o[e] = acc;
+                }
+            }
+        }
+    }
+}
