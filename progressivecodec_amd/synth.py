@@ -23,7 +23,8 @@ from .arch import CodecConfig, param_spec
 
 _PED = float((2.0 ** -18) ** 2)  # parametrizers.py:27-30
 # amplification recipe (tuned through the real reference: index histogram 0..27, bypass rate ~0.3 %)
-AMP_Y, AMP_Z, AMP_S, BIAS_S = 0.8, 6.0, 2.0, 0.6
+AMP_Y, AMP_Z, AMP_S, BIAS_S = 0.8, 4.0, 2.0, 0.6
+AMP_HS, AMP_M = 0.15, 1.0
 
 
 def _rng(name: str, seed: int):
@@ -68,6 +69,10 @@ def synthetic_state_dict(cfg: CodecConfig = CodecConfig(), seed: int = 0, as_tor
                 w *= AMP_Z       # hyper-latent z spread over a few integers
             if name.endswith(".8.weight") and name.startswith("cc_scale_transforms"):
                 w *= AMP_S       # spread the predicted scales over the table
+            if name.endswith(".8.weight") and name.startswith("cc_mean_transforms"):
+                w *= AMP_M       # keep the predicted means below the latent amplitude
+            if name.endswith(".8.weight") and name.startswith(("h_mean_s", "h_scale_s")):
+                w *= AMP_HS      # hyper-synthesis output amplitude (interior-pixel limit)
             v = w
         elif kind == "deconv_w":
             ci, co, kh, kw = shape
