@@ -1,0 +1,175 @@
+/* pcodec.h -- C ABI of libpcodec.so, the MI355X-native encode/decode hot path of
+ * EIDOSLAB/ProgressiveCodec (ChannelProgresssiveWACNN.compress()/decompress()).
+ *
+ * Plain C: pointers, sizes and integer status codes only; no C++/torch types cross the
+ * boundary.  Device pointers are HIP device pointers, `stream` arguments are hipStream_t
+ * passed as void* (NULL = default stream).  Every function returns PC_OK (0) or a negative
+ * PC_ERR_* code and never aborts.  Functions are re-entrant for distinct objects/buffers.
+ *
+ * Each entry point names the reference interface it replaces (paths under
+ * /root/reference/src/compress).  INTEGRATION.md shows the ctypes binding a maintainer of
+ * the reference would add.
+ */
+#ifndef PCODEC_H
+#define PCODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define PC_API __attribute__((visibility("default")))
+#else
+#define PC_API
+#endif
+
+enum {
+    PC_OK = 0,
+    PC_ERR_ARG = -1,        /* invalid argument / unsupported shape (reference: ValueError, entropy_models.py:214-224) */
+    PC_ERR_INDEX = -2,      /* CDF index out of range (reference: assert, rans_interface.cpp:110-111) */
+    PC_ERR_BUFFER = -3,     /* output buffer too small */
+    PC_ERR_TRUNCATED = -4,  /* bitstream shorter than the symbols it should hold */
+    PC_ERR_CDF = -5,        /* malformed CDF / pmf (reference: assert, ops.cpp:45; rans_interface.cpp:48-57) */
+    PC_ERR_HIP = -6,        /* HIP runtime error (see pc_last_hip_error) */
+    PC_ERR_NOMEM = -7,
+    PC_ERR_STATE = -8,      /* object not ready (e.g. tables not set: "Uninitialized CDFs. Run update() first") */
+    PC_ERR_MISSING = -9     /* state_dict tensor missing or wrong shape */
+};
+
+PC_API const char* pc_version(void);
+PC_API const char* pc_strerror(int code);
+PC_API int pc_last_hip_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Entropy coder (host).  rANS: 64-bit state, 32-bit words, 16-bit precision, 4-bit bypass.
+ * ------------------------------------------------------------------------------------- */
+
+/* Upper bound in bytes of one encoded stream of n symbols (worst case all-bypass). */
+PC_API size_t pc_rans_bound(size_t n);
+
+/* Replaces compressai.ans.RansEncoder.encode_with_indexes (cpp_exts/rans/rans_interface.cpp:193-204,
+ * i.e. BufferedRansEncoder::encode_with_indexes :99-164 + flush :166-191).
+ * cdfs is a dense [n_cdf][cdf_stride] int32 table (the module buffer `_quantized_cdf`),
+ * cdf_sizes = `_cdf_length`, offsets = `_offset`.  Output bytes are identical to the reference's. */
+PC_API int pc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, size_t n,
+                                       const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                       const int32_t* cdf_sizes, const int32_t* offsets,
+                                       uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* Replaces compressai.ans.RansDecoder.decode_with_indexes (rans_interface.cpp:206-275). */
+PC_API int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encoded_len,
+                                       const int32_t* indexes, size_t n,
+                                       const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                       const int32_t* cdf_sizes, const int32_t* offsets,
+                                       int32_t* symbols_out);
+
+/* Batched forms: n_streams independent streams of n symbols each (one per image, as the loop at
+ * entropy_models.py:227-235 / :276-286 produces), coded on a host thread pool.
+ * symbols/indexes: [n_streams][n].  Encode writes stream s at out + s*out_stride. */
+PC_API int pc_rans_encode_batch(const int32_t* symbols, const int32_t* indexes, size_t n_streams, size_t n,
+                                const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                const int32_t* cdf_sizes, const int32_t* offsets,
+                                uint8_t* out, size_t out_stride, size_t* out_lens, int n_threads);
+PC_API int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams,
+                                const int32_t* indexes, size_t n,
+                                const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                const int32_t* cdf_sizes, const int32_t* offsets,
+                                int32_t* symbols_out, int n_threads);
+
+/* Replaces compressai._CXX.pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp:10-67).  cdf_out has n+1 entries. */
+PC_API int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf_out);
+
+/* ---------------------------------------------------------------------------------------
+ * Device stages (asynchronous on `stream`).  Activations are NHWC float32.
+ * ------------------------------------------------------------------------------------- */
+
+/* Generic convolution / transposed convolution / linear layer with the reference's weight layout.
+ *   kind 0: nn.Conv2d weight [Cout][Cin][k][k], stride s, padding k/2   (models/utils.py:186, layers/layers.py:15,27)
+ *   kind 1: nn.ConvTranspose2d(k=5, s=2, p=2, output_padding=1) weight [Cin][Cout][5][5]   (models/utils.py:196)
+ * `w_packed` must come from pc_pack_conv_weight (device, tap-major [taps][Cin][Cout]).
+ * act: 0 none, 1 GELU.  x: [B][H][W][Cin], out: [B][Ho][Wo][Cout]. */
+PC_API int pc_pack_conv_weight(const float* w_host, int kind, int Cout, int Cin, int k, float* w_packed_host);
+PC_API int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin,
+                          const float* w_packed, const float* bias, int kind, int Cout, int k, int stride,
+                          int act, int tile_cfg, float* out, void* stream);
+
+/* GDN / IGDN (layers/gdn.py:50-63) with already re-parametrised beta [C], gamma_t [C_in][C_out] = gamma^T. */
+PC_API int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma_t,
+                       int inverse, float* out, void* stream);
+
+/* Shifted-window attention core between the qkv and proj Linears (layers/win_attention.py:84-115,153-207).
+ * qkv: [B][H][W][3C]; bias: dense [heads][T][T]; out: [B][H][W][C]. */
+PC_API int pc_win_attention_nhwc(const float* qkv, const float* bias, int B, int H, int W, int C, int heads,
+                                 int window, int shift, float* out, void* stream);
+
+/* ChannelMask "point-based-std" threshold (layers/masking.py:205-223): thr[b] = torch.quantile(scale[b].ravel(), q).
+ * scale: [B][HW][C] with pixel stride ld. */
+PC_API int pc_mask_quantile_threshold(const float* scale, int ld, int B, int HW, int C, float q, float* thr, void* stream);
+
+/* Fused mask -> index -> quantise -> dequantise of one 32-channel slice (encoder side):
+ *   mask = scale >= thr[b]                      (masking.py:219; mask_mode 1; 0 = no mask, 2 = ones, 3 = zeros)
+ *   idx  = build_indexes(scale * mask)          (entropy_models.py:661-666; CHProg_cnn.py:751,828)
+ *   sym  = int(round((y [- ybase] - mu) [* mask]))   (entropy_models.py:137-150; CHProg_cnn.py:752,780-781,830)
+ *   yhat = float(sym) + mu                      (CHProg_cnn.py:754-755,833-834)
+ * scale/mu/y/ybase/yhat NHWC with their own pixel strides; sym/idx/mask out in [B][32][HW] (rANS order). */
+PC_API int pc_gc_prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu,
+                             const float* y, int ld_y, const float* ybase, int ld_ybase,
+                             const float* thr, int mask_mode, int B, int HW,
+                             const float* scale_table, int n_table, float scale_bound,
+                             int32_t* sym, int32_t* idx, float* mask, float* yhat, int ld_yhat, void* stream);
+PC_API int pc_gc_prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW,
+                                   const float* scale_table, int n_table, float scale_bound,
+                                   int32_t* idx, float* mask, void* stream);
+PC_API int pc_gc_dequantize(const int32_t* sym, const float* mu, int ld_mu, int B, int HW,
+                            float* yhat, int ld_yhat, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The codec object: ChannelProgresssiveWACNN (models/CHProg_cnn.py:30) in the canonical
+ * configuration, weights resident in HBM, compress()/decompress() as native launch sequences.
+ * ------------------------------------------------------------------------------------- */
+typedef struct pc_codec pc_codec;
+
+enum { PC_MASK_POINT_BASED_STD = 0, PC_MASK_TWO_LEVELS = 1 };
+enum { PC_F32 = 0, PC_I32 = 1, PC_I64 = 2 };
+
+PC_API int pc_codec_create(pc_codec** out, int device);
+PC_API void pc_codec_destroy(pc_codec* c);
+
+/* load_state_dict (models/cnn.py:195-202): one call per reference state_dict key, host pointers.
+ * Unknown keys are ignored (returns PC_OK); shape mismatches return PC_ERR_MISSING. */
+PC_API int pc_codec_set_tensor(pc_codec* c, const char* name, const void* data, int dtype,
+                               const int64_t* shape, int ndim);
+/* Entropy tables: the module buffers _quantized_cdf/_cdf_length/_offset after update() (models/cnn.py:137-142). */
+PC_API int pc_codec_set_tables(pc_codec* c, int which /*0 = gaussian_conditional, 1 = entropy_bottleneck*/,
+                               const int32_t* cdf, int n_cdf, int cdf_stride, const int32_t* cdf_sizes,
+                               const int32_t* offsets);
+/* Validate that every tensor is present, fold the GDN re-parametrisation, pack weights into HBM. */
+PC_API int pc_codec_finalize(pc_codec* c);
+PC_API int pc_codec_set_threads(pc_codec* c, int n_threads);
+
+/* compress (models/CHProg_cnn.py:686-847).  x: device, NCHW [B][3][H][W], H and W multiples of 64.
+ * On success the codec holds n_slices*B + B byte strings (n_slices = 10 for quality <= 0, else 20) until
+ * the next call; masks_out (device, [10][B][32][H/16][W/16], may be NULL) receives the "masks" entry. */
+PC_API int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
+                             float* masks_out, void* stream);
+PC_API int pc_codec_num_slices(const pc_codec* c);
+/* string of y slice `slice` (0..n_slices-1) or of z (slice = -1) for image b */
+PC_API int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len);
+
+/* decompress (models/CHProg_cnn.py:849-999).  y_strings: [n_slices][B] pointers (slice-major), z_strings: [B];
+ * zh, zw = "shape"; x_hat: device NCHW [B][3][64*zh][64*zw]. */
+PC_API int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens, int n_slices,
+                               const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
+                               double quality, int mask_pol, float* x_hat, void* stream);
+
+/* Debug/test taps: copy an internal device tensor of the last call to host ("y", "z", "latent_means", ...). */
+PC_API int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap_floats, size_t* n_floats);
+PC_API int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* host_out, size_t cap, size_t* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCODEC_H */

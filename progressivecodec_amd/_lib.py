@@ -1,0 +1,83 @@
+"""ctypes binding of libpcodec.so (include/pcodec.h).  There is no fallback: if the
+library is missing the import fails, and creating a codec without a HIP device fails."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpcodec.so")
+
+PC_OK = 0
+ERRORS = {-1: "PC_ERR_ARG", -2: "PC_ERR_INDEX", -3: "PC_ERR_BUFFER", -4: "PC_ERR_TRUNCATED", -5: "PC_ERR_CDF",
+          -6: "PC_ERR_HIP", -7: "PC_ERR_NOMEM", -8: "PC_ERR_STATE", -9: "PC_ERR_MISSING"}
+
+#: every symbol include/pcodec.h declares (tests check the library exports all of them)
+EXPORTS = [
+    "pc_version", "pc_strerror", "pc_last_hip_error", "pc_rans_bound", "pc_rans_encode_with_indexes",
+    "pc_rans_decode_with_indexes", "pc_rans_encode_batch", "pc_rans_decode_batch", "pc_pmf_to_quantized_cdf",
+    "pc_pack_conv_weight", "pc_conv2d_nhwc", "pc_gdn_nhwc", "pc_win_attention_nhwc", "pc_mask_quantile_threshold",
+    "pc_gc_prep_encode", "pc_gc_prep_decode_index", "pc_gc_dequantize", "pc_codec_create", "pc_codec_destroy",
+    "pc_codec_set_tensor", "pc_codec_set_tables", "pc_codec_finalize", "pc_codec_set_threads", "pc_codec_compress",
+    "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
+]
+
+
+class PcodecError(RuntimeError):
+    def __init__(self, code, where=""):
+        self.code = code
+        msg = lib().pc_strerror(code).decode() if _lib is not None else ""
+        hip = lib().pc_last_hip_error() if (_lib is not None and code == -6) else 0
+        super().__init__(f"{where}: {ERRORS.get(code, code)} ({msg})" + (f" hipError={hip}" if hip else ""))
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  progressivecodec_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        vp, i32p, f32p, u8p, sz = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_size_t
+        L.pc_version.restype = C.c_char_p
+        L.pc_strerror.restype = C.c_char_p
+        L.pc_strerror.argtypes = [C.c_int]
+        L.pc_rans_bound.restype = sz
+        L.pc_rans_bound.argtypes = [sz]
+        L.pc_rans_encode_with_indexes.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp, sz, C.POINTER(sz)]
+        L.pc_rans_decode_with_indexes.argtypes = [vp, sz, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.pc_rans_encode_batch.argtypes = [vp, vp, sz, sz, vp, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.c_int]
+        L.pc_rans_decode_batch.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
+        L.pc_pmf_to_quantized_cdf.argtypes = [vp, C.c_int, C.c_int, vp]
+        L.pc_pack_conv_weight.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]
+        L.pc_conv2d_nhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, C.c_int, vp, vp]
+        L.pc_gdn_nhwc.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, vp, vp]
+        L.pc_win_attention_nhwc.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
+        L.pc_mask_quantile_threshold.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, vp]
+        L.pc_gc_prep_encode.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int,
+                                        vp, C.c_int, C.c_float, vp, vp, vp, vp, C.c_int, vp]
+        L.pc_gc_prep_decode_index.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp]
+        L.pc_gc_dequantize.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, vp]
+        L.pc_codec_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.pc_codec_destroy.argtypes = [vp]
+        L.pc_codec_destroy.restype = None
+        L.pc_codec_set_tensor.argtypes = [vp, C.c_char_p, vp, C.c_int, C.POINTER(C.c_int64), C.c_int]
+        L.pc_codec_set_tables.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+        L.pc_codec_finalize.argtypes = [vp]
+        L.pc_codec_set_threads.argtypes = [vp, C.c_int]
+        L.pc_codec_compress.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp]
+        L.pc_codec_num_slices.argtypes = [vp]
+        L.pc_codec_get_string.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.pc_codec_decompress.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp]
+        L.pc_codec_read_tap.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
+        L.pc_codec_read_tap_i32.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
+        _lib = L
+    return _lib
+
+
+def check(code, where=""):
+    if code != PC_OK:
+        raise PcodecError(code, where)

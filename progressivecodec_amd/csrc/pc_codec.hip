@@ -1,0 +1,925 @@
+// pc_codec.hip -- native runtime of ChannelProgresssiveWACNN.compress()/decompress()
+// (reference: /root/reference/src/compress/models/CHProg_cnn.py:686-999) for the canonical
+// configuration, as HIP launch sequences over HBM-resident weights.
+//
+// Data layout in HBM
+//   * activations NHWC float32; the 640-channel latent y, the hyper-synthesis outputs
+//     latent_means / latent_scales ([M][640]) and the decoded slices (y_hat base / enhancement,
+//     [M][320] each) are single buffers; the reference's torch.cat() supports are expressed as
+//     channel *segments* of these buffers handed to the conv kernel (no copies).
+//   * conv weights tap-major [tap][Cin][Cout] (N contiguous = GEMM B operand rows).
+//   * symbols / indexes [slice][B][32][h*w] int32 = the rANS coder's C,H,W raster order.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <new>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/pcodec.h"
+#include "pc_device.h"
+#include "pc_host.h"
+
+static thread_local int g_last_hip = 0;
+#define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { g_last_hip = (int)_e; return PC_ERR_HIP; } } while (0)
+#define PCCHK(expr) do { int _r = (expr); if (_r != PC_OK) return _r; } while (0)
+
+extern "C" int pc_last_hip_error(void) { return g_last_hip; }
+
+namespace {
+
+constexpr int NS0 = 10, D0 = 320, MLAT = 640, NCH = 192, HEADS = 8, SLICE = 32;
+const int CC_W[5] = {224, 176, 128, 64, 32};
+
+struct HostTensor { std::vector<uint8_t> data; std::vector<int64_t> shape; int dtype; };
+
+struct ConvW { float* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, k = 0, kind = 0; };
+struct GdnW { float* beta = nullptr; float* gamma_t = nullptr; int C = 0; };
+struct RuW { ConvW c0, c2, c4; };
+struct WamW { RuW a[3], b[3]; ConvW qkv, proj, out; float* bias = nullptr; int C = 0, ws = 0, shift = 0; };
+struct Stack5W { ConvW c[5]; };
+struct HsW { ConvW c0, c2, c4, c6, c8; };
+struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };
+
+struct Tables {
+    std::vector<int32_t> cdf, len, off;
+    int n = 0, stride = 0;
+    bool ok() const { return n > 0; }
+};
+
+struct DevBuf { void* p = nullptr; size_t bytes = 0; };
+
+}  // namespace
+
+struct pc_codec {
+    int device = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> sd;
+    std::vector<void*> weight_allocs;
+    std::map<std::string, DevBuf> bufs;          // grow-only named workspace
+    // network
+    ConvW ga0, ga2, ga5, ga7; GdnW ga1, ga3, ga6; WamW ga4, ga8;
+    GsW gs[2];
+    ConvW ha[5];
+    HsW hms[2], hss[2];
+    Stack5W cc_mean[NS0], cc_scale[NS0], lrp[NS0], cc_mean_p[NS0], cc_scale_p[NS0], lrp_p[NS0];
+    float* medians = nullptr;                    // [192] device
+    float* scale_table = nullptr;                // [64] device
+    int n_table = 0;
+    float scale_bound = 0.11f;
+    Tables gc, eb;
+    // pinned host staging
+    int32_t* h_sym = nullptr; int32_t* h_idx = nullptr; size_t h_cap = 0;
+    // results of the last compress
+    int res_slices = 0, res_B = 0;
+    std::vector<std::vector<uint8_t>> y_strings;  // [slice*B + b]
+    std::vector<std::vector<uint8_t>> z_strings;  // [b]
+    int n_threads = 0;
+    // last-call geometry for taps
+    int last_B = 0, last_h16 = 0, last_w16 = 0;
+
+    template <typename T> int buf(const std::string& name, size_t count, T** out)
+    {
+        DevBuf& d = bufs[name];
+        const size_t need = count * sizeof(T);
+        if (d.bytes < need) {
+            if (d.p) (void)hipFree(d.p);
+            d.p = nullptr; d.bytes = 0;
+            HIPCHK(hipMalloc(&d.p, need));
+            d.bytes = need;
+        }
+        *out = reinterpret_cast<T*>(d.p);
+        return PC_OK;
+    }
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ weights
+const HostTensor* find(const pc_codec* c, const std::string& k, int dtype, std::initializer_list<int64_t> shape)
+{
+    auto it = c->sd.find(k);
+    if (it == c->sd.end() || it->second.dtype != dtype) return nullptr;
+    if (it->second.shape.size() != shape.size()) return nullptr;
+    size_t i = 0;
+    for (int64_t s : shape) if (it->second.shape[i++] != s) return nullptr;
+    return &it->second;
+}
+
+int upload(pc_codec* c, const std::vector<float>& h, float** dev)
+{
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, std::max<size_t>(h.size(), 4) * sizeof(float)));
+    HIPCHK(hipMemcpy(p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    c->weight_allocs.push_back(p);
+    *dev = reinterpret_cast<float*>(p);
+    return PC_OK;
+}
+
+int load_conv(pc_codec* c, const std::string& p, int Cin, int Cout, int k, int kind, ConvW* out)
+{
+    const HostTensor* w = kind == 0 ? find(c, p + ".weight", PC_F32, {Cout, Cin, k, k}) : find(c, p + ".weight", PC_F32, {Cin, Cout, k, k});
+    const HostTensor* b = find(c, p + ".bias", PC_F32, {Cout});
+    if (!w || !b) { std::fprintf(stderr, "[pcodec] missing/mis-shaped tensor %s\n", p.c_str()); return PC_ERR_MISSING; }
+    std::vector<float> packed((size_t)k * k * Cin * Cout);
+    PCCHK(pc_pack_conv_weight(reinterpret_cast<const float*>(w->data.data()), kind, Cout, Cin, k, packed.data()));
+    PCCHK(upload(c, packed, &out->w));
+    std::vector<float> bias(reinterpret_cast<const float*>(b->data.data()), reinterpret_cast<const float*>(b->data.data()) + Cout);
+    PCCHK(upload(c, bias, &out->b));
+    out->Cin = Cin; out->Cout = Cout; out->k = k; out->kind = kind;
+    return PC_OK;
+}
+
+int load_linear(pc_codec* c, const std::string& p, int Cin, int Cout, ConvW* out)     // nn.Linear weight [out][in]
+{
+    const HostTensor* w = find(c, p + ".weight", PC_F32, {Cout, Cin});
+    const HostTensor* b = find(c, p + ".bias", PC_F32, {Cout});
+    if (!w || !b) { std::fprintf(stderr, "[pcodec] missing/mis-shaped tensor %s\n", p.c_str()); return PC_ERR_MISSING; }
+    std::vector<float> packed((size_t)Cin * Cout);
+    PCCHK(pc_pack_conv_weight(reinterpret_cast<const float*>(w->data.data()), 0, Cout, Cin, 1, packed.data()));
+    PCCHK(upload(c, packed, &out->w));
+    std::vector<float> bias(reinterpret_cast<const float*>(b->data.data()), reinterpret_cast<const float*>(b->data.data()) + Cout);
+    PCCHK(upload(c, bias, &out->b));
+    out->Cin = Cin; out->Cout = Cout; out->k = 1; out->kind = 0;
+    return PC_OK;
+}
+
+// NonNegativeParametrizer.forward (ops/parametrizers.py:46-49): max(x, bound)^2 - pedestal, in float32
+int load_gdn(pc_codec* c, const std::string& p, int C, GdnW* out)
+{
+    const HostTensor* beta = find(c, p + ".beta", PC_F32, {C});
+    const HostTensor* gamma = find(c, p + ".gamma", PC_F32, {C, C});
+    const HostTensor* bb = find(c, p + ".beta_reparam.lower_bound.bound", PC_F32, {1});
+    const HostTensor* bp = find(c, p + ".beta_reparam.pedestal", PC_F32, {1});
+    const HostTensor* gb = find(c, p + ".gamma_reparam.lower_bound.bound", PC_F32, {1});
+    const HostTensor* gp = find(c, p + ".gamma_reparam.pedestal", PC_F32, {1});
+    if (!beta || !gamma || !bb || !bp || !gb || !gp) { std::fprintf(stderr, "[pcodec] missing GDN tensors %s\n", p.c_str()); return PC_ERR_MISSING; }
+    auto f = [](const HostTensor* t) { return reinterpret_cast<const float*>(t->data.data()); };
+    std::vector<float> hb(C), hg((size_t)C * C);
+    for (int i = 0; i < C; ++i) { const float v = std::max(f(beta)[i], f(bb)[0]); hb[i] = v * v - f(bp)[0]; }
+    for (int i = 0; i < C; ++i)
+        for (int j = 0; j < C; ++j) { const float v = std::max(f(gamma)[(size_t)i * C + j], f(gb)[0]); hg[(size_t)j * C + i] = v * v - f(gp)[0]; }
+    PCCHK(upload(c, hb, &out->beta));
+    PCCHK(upload(c, hg, &out->gamma_t));
+    out->C = C;
+    return PC_OK;
+}
+
+int load_ru(pc_codec* c, const std::string& p, int C, RuW* r)
+{
+    PCCHK(load_conv(c, p + ".conv.0", C, C / 2, 1, 0, &r->c0));
+    PCCHK(load_conv(c, p + ".conv.2", C / 2, C / 2, 3, 0, &r->c2));
+    PCCHK(load_conv(c, p + ".conv.4", C / 2, C, 1, 0, &r->c4));
+    return PC_OK;
+}
+
+int load_wam(pc_codec* c, const std::string& p, int C, int ws, int shift, WamW* w)
+{
+    w->C = C; w->ws = ws; w->shift = shift;
+    for (int i = 0; i < 3; ++i) PCCHK(load_ru(c, p + ".conv_a." + std::to_string(i), C, &w->a[i]));
+    for (int i = 0; i < 3; ++i) PCCHK(load_ru(c, p + ".conv_b." + std::to_string(i + 1), C, &w->b[i]));
+    PCCHK(load_linear(c, p + ".conv_b.0.attn.qkv", C, 3 * C, &w->qkv));
+    PCCHK(load_linear(c, p + ".conv_b.0.attn.proj", C, C, &w->proj));
+    PCCHK(load_conv(c, p + ".conv_b.4", C, C, 1, 0, &w->out));
+    const int T = ws * ws, R = (2 * ws - 1) * (2 * ws - 1);
+    const HostTensor* tab = find(c, p + ".conv_b.0.attn.relative_position_bias_table", PC_F32, {R, HEADS});
+    const HostTensor* idx = find(c, p + ".conv_b.0.attn.relative_position_index", PC_I64, {T, T});
+    if (!tab || !idx) { std::fprintf(stderr, "[pcodec] missing attention tables %s\n", p.c_str()); return PC_ERR_MISSING; }
+    // dense bias[h][i][j] = table[index[i][j]][h]   (win_attention.py:97-100)
+    std::vector<float> dense((size_t)HEADS * T * T);
+    const float* t = reinterpret_cast<const float*>(tab->data.data());
+    const int64_t* ix = reinterpret_cast<const int64_t*>(idx->data.data());
+    for (int i = 0; i < T; ++i)
+        for (int j = 0; j < T; ++j) {
+            const int64_t r = ix[(size_t)i * T + j];
+            if (r < 0 || r >= R) return PC_ERR_MISSING;
+            for (int h = 0; h < HEADS; ++h) dense[((size_t)h * T + i) * T + j] = t[r * HEADS + h];
+        }
+    PCCHK(upload(c, dense, &w->bias));
+    return PC_OK;
+}
+
+int load_stack5(pc_codec* c, const std::string& p, int Cin, Stack5W* s)
+{
+    int ci = Cin;
+    for (int j = 0; j < 5; ++j) { PCCHK(load_conv(c, p + "." + std::to_string(2 * j), ci, CC_W[j], 3, 0, &s->c[j])); ci = CC_W[j]; }
+    return PC_OK;
+}
+
+int load_hs(pc_codec* c, const std::string& p, HsW* h)
+{
+    PCCHK(load_conv(c, p + ".0", NCH, 192, 3, 0, &h->c0));
+    PCCHK(load_conv(c, p + ".2.0", 192, 224 * 4, 3, 0, &h->c2));
+    PCCHK(load_conv(c, p + ".4", 224, 256, 3, 0, &h->c4));
+    PCCHK(load_conv(c, p + ".6.0", 256, 288 * 4, 3, 0, &h->c6));
+    PCCHK(load_conv(c, p + ".8", 288, D0, 3, 0, &h->c8));
+    return PC_OK;
+}
+
+// ------------------------------------------------------------------------------------------ launch helpers
+struct Seg { const float* p; int ld; int nch; };
+
+void fill_conv_taps(pc_conv_params& q, int k, int stride)
+{
+    const int pad = k / 2;
+    q.nphase = 1; q.ntap[0] = k * k; q.stride = stride;
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx) {
+            const int t = ky * k + kx;
+            q.dy[0][t] = (int8_t)(ky - pad); q.dx[0][t] = (int8_t)(kx - pad); q.wtap[0][t] = t;
+        }
+    q.osy = q.osx = 1; q.ooy[0] = q.oox[0] = 0;
+}
+
+void fill_deconv_taps(pc_conv_params& q)   // ConvTranspose2d(5, s2, p2, op1) as 4 output phases
+{
+    q.nphase = 4; q.stride = 1; q.osy = q.osx = 2;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int ph = py * 2 + px;
+            int t = 0;
+            for (int ky = py; ky < 5; ky += 2)
+                for (int kx = px; kx < 5; kx += 2) {
+                    q.dy[ph][t] = (int8_t)((py + 2 - ky) / 2); q.dx[ph][t] = (int8_t)((px + 2 - kx) / 2);
+                    q.wtap[ph][t] = ky * 5 + kx;
+                    ++t;
+                }
+            q.ntap[ph] = t; q.ooy[ph] = py; q.oox[ph] = px;
+        }
+}
+
+// generic conv over NHWC segments -> NHWC output slice (channel offset folded into `out`, pixel stride ldo)
+int conv(hipStream_t st, const ConvW& w, std::initializer_list<Seg> segs, int B, int H, int W, int stride,
+         float* out, int ldo, int epi, const float* aux0 = nullptr, int ld0 = 0, const float* aux1 = nullptr, int ld1 = 0,
+         bool pixel_shuffle = false)
+{
+    pc_conv_params q;
+    std::memset(&q, 0, sizeof(q));
+    int cin = 0;
+    for (const Seg& s : segs) {
+        if (s.nch == 0) continue;
+        if (q.nseg >= PC_MAX_SEG) return PC_ERR_ARG;
+        q.seg[q.nseg].ptr = s.p; q.seg[q.nseg].ld = s.ld; q.seg[q.nseg].nch = s.nch; ++q.nseg; cin += s.nch;
+    }
+    if (cin != w.Cin) return PC_ERR_ARG;
+    q.Cin = cin; q.B = B; q.H = H; q.W = W;
+    q.w = w.w; q.bias = w.b; q.Cout = w.Cout;
+    q.epi = epi; q.aux0 = aux0; q.ld0 = ld0; q.aux1 = aux1; q.ld1 = ld1;
+    q.out = out;
+    if (w.kind == 0) {
+        fill_conv_taps(q, w.k, stride);
+        q.Ho = (H + 2 * (w.k / 2) - w.k) / stride + 1;
+        q.Wo = (W + 2 * (w.k / 2) - w.k) / stride + 1;
+        q.outH = q.Ho; q.outW = q.Wo;
+    } else {
+        fill_deconv_taps(q);
+        q.Ho = H; q.Wo = W; q.outH = 2 * H; q.outW = 2 * W;
+    }
+    q.M = B * q.Ho * q.Wo;
+    q.pixel_shuffle = pixel_shuffle ? 1 : 0;
+    if (pixel_shuffle) { q.outH *= 2; q.outW *= 2; }
+    q.out_sc = 1; q.out_sx = ldo; q.out_sy = (int64_t)q.outW * ldo; q.out_sb = (int64_t)q.outH * q.outW * ldo;
+    return pc_conv_launch(q, st);
+}
+
+int gdn(hipStream_t st, const GdnW& g, const float* x, int B, int H, int W, bool inverse, float* out)
+{
+    pc_conv_params q;
+    std::memset(&q, 0, sizeof(q));
+    q.nseg = 1; q.seg[0].ptr = x; q.seg[0].ld = g.C; q.seg[0].nch = g.C; q.Cin = g.C;
+    q.B = B; q.H = H; q.W = W; q.square = 1;
+    fill_conv_taps(q, 1, 1);
+    q.w = g.gamma_t; q.bias = g.beta; q.Cout = g.C;
+    q.Ho = H; q.Wo = W; q.outH = H; q.outW = W; q.M = B * H * W;
+    q.out = out; q.out_sc = 1; q.out_sx = g.C; q.out_sy = (int64_t)W * g.C; q.out_sb = (int64_t)H * W * g.C;
+    q.epi = inverse ? PC_EPI_IGDN : PC_EPI_GDN; q.aux0 = x; q.ld0 = g.C;
+    return pc_conv_launch(q, st);
+}
+
+// ResidualUnit (layers/layers.py:38-57): x -> gelu(conv1x1) -> gelu(conv3x3) -> conv1x1 + x -> gelu
+int ru(hipStream_t st, const RuW& r, const float* x, int C, int B, int H, int W, float* t1, float* t2, float* out)
+{
+    PCCHK(conv(st, r.c0, {{x, C, C}}, B, H, W, 1, t1, C / 2, PC_EPI_GELU));
+    PCCHK(conv(st, r.c2, {{t1, C / 2, C / 2}}, B, H, W, 1, t2, C / 2, PC_EPI_GELU));
+    PCCHK(conv(st, r.c4, {{t2, C / 2, C / 2}}, B, H, W, 1, out, C, PC_EPI_RES_GELU, x, C));
+    return PC_OK;
+}
+
+// Win_noShift_Attention (layers/layers.py:59-75)
+int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H, int W, float* out)
+{
+    const int C = w.C;
+    const size_t M = (size_t)B * H * W;
+    float *t1, *t2, *a0, *a1, *qkv, *o;
+    PCCHK(c->buf("wam_t1", M * (C / 2), &t1));
+    PCCHK(c->buf("wam_t2", M * (C / 2), &t2));
+    PCCHK(c->buf("wam_a0", M * C, &a0));
+    PCCHK(c->buf("wam_a1", M * C, &a1));
+    PCCHK(c->buf("wam_b0", M * C, &o));
+    PCCHK(c->buf("wam_qkv", M * 3 * C, &qkv));
+    float* b1;
+    PCCHK(c->buf("wam_b1", M * C, &b1));
+    // branch a: three residual units
+    PCCHK(ru(st, w.a[0], x, C, B, H, W, t1, t2, a0));
+    PCCHK(ru(st, w.a[1], a0, C, B, H, W, t1, t2, a1));
+    PCCHK(ru(st, w.a[2], a1, C, B, H, W, t1, t2, a0));                  // a in a0
+    // branch b: window attention, three residual units, 1x1
+    PCCHK(conv(st, w.qkv, {{x, C, C}}, B, H, W, 1, qkv, 3 * C, PC_EPI_NONE));
+    PCCHK(pc_win_attention_launch(qkv, w.bias, B, H, W, C, HEADS, w.ws, w.shift, 1.0f / std::sqrt((float)(C / HEADS)), a1, st));
+    PCCHK(conv(st, w.proj, {{a1, C, C}}, B, H, W, 1, o, C, PC_EPI_RES, x, C));     // shortcut + proj(attn)
+    PCCHK(ru(st, w.b[0], o, C, B, H, W, t1, t2, b1));
+    PCCHK(ru(st, w.b[1], b1, C, B, H, W, t1, t2, o));
+    PCCHK(ru(st, w.b[2], o, C, B, H, W, t1, t2, b1));
+    PCCHK(conv(st, w.out, {{b1, C, C}}, B, H, W, 1, out, C, PC_EPI_GATE, a0, C, x, C));   // a * sigmoid(b) + x
+    return PC_OK;
+}
+
+int stack5(pc_codec* c, hipStream_t st, const Stack5W& s, std::initializer_list<Seg> segs, int B, int h, int w,
+           float* out, int ldo, int epi, const float* aux0 = nullptr, int ld0 = 0, const float* aux1 = nullptr, int ld1 = 0,
+           const char* tag = "s5")
+{
+    const size_t M = (size_t)B * h * w;
+    float *t0, *t1;
+    PCCHK(c->buf(std::string(tag) + "_t0", M * 224, &t0));
+    PCCHK(c->buf(std::string(tag) + "_t1", M * 176, &t1));
+    PCCHK(conv(st, s.c[0], segs, B, h, w, 1, t0, 224, PC_EPI_GELU));
+    PCCHK(conv(st, s.c[1], {{t0, 224, 224}}, B, h, w, 1, t1, 176, PC_EPI_GELU));
+    PCCHK(conv(st, s.c[2], {{t1, 176, 176}}, B, h, w, 1, t0, 128, PC_EPI_GELU));
+    PCCHK(conv(st, s.c[3], {{t0, 128, 128}}, B, h, w, 1, t1, 64, PC_EPI_GELU));
+    PCCHK(conv(st, s.c[4], {{t1, 64, 64}}, B, h, w, 1, out, ldo, epi, aux0, ld0, aux1, ld1));
+    return PC_OK;
+}
+
+// hyper-synthesis net (CHProg_cnn.py:208-232): z_hat [B][zh][zw][192] -> out slice [B][4zh][4zw][320] (ld 640)
+int hs(pc_codec* c, hipStream_t st, const HsW& h, const float* z, int B, int zh, int zw, float* out, int ldo)
+{
+    const size_t M = (size_t)B * zh * zw;
+    float *t0, *t1, *t2, *t3;
+    PCCHK(c->buf("hs_t0", M * 192, &t0));
+    PCCHK(c->buf("hs_t1", M * 4 * 224, &t1));
+    PCCHK(c->buf("hs_t2", M * 4 * 256, &t2));
+    PCCHK(c->buf("hs_t3", M * 16 * 288, &t3));
+    PCCHK(conv(st, h.c0, {{z, 192, 192}}, B, zh, zw, 1, t0, 192, PC_EPI_GELU));
+    PCCHK(conv(st, h.c2, {{t0, 192, 192}}, B, zh, zw, 1, t1, 224, PC_EPI_GELU, nullptr, 0, nullptr, 0, true));
+    PCCHK(conv(st, h.c4, {{t1, 224, 224}}, B, 2 * zh, 2 * zw, 1, t2, 256, PC_EPI_GELU));
+    PCCHK(conv(st, h.c6, {{t2, 256, 256}}, B, 2 * zh, 2 * zw, 1, t3, 288, PC_EPI_GELU, nullptr, 0, nullptr, 0, true));
+    PCCHK(conv(st, h.c8, {{t3, 288, 288}}, B, 4 * zh, 4 * zw, 1, out, ldo, PC_EPI_NONE));
+    return PC_OK;
+}
+
+int g_a(pc_codec* c, hipStream_t st, const float* x, int B, int H, int W, float* y)
+{
+    float *t0, *t1, *t2, *t3, *t4;
+    PCCHK(c->buf("ga_t0", (size_t)B * (H / 2) * (W / 2) * NCH, &t0));
+    PCCHK(c->buf("ga_t1", (size_t)B * (H / 2) * (W / 2) * NCH, &t1));
+    PCCHK(c->buf("ga_t2", (size_t)B * (H / 4) * (W / 4) * NCH, &t2));
+    PCCHK(c->buf("ga_t3", (size_t)B * (H / 4) * (W / 4) * NCH, &t3));
+    PCCHK(c->buf("ga_t4", (size_t)B * (H / 16) * (W / 16) * MLAT, &t4));
+    {   // conv 3 -> 192, 5x5 s2, reading the NCHW image directly (element-wise gather path)
+        pc_conv_params q;
+        std::memset(&q, 0, sizeof(q));
+        q.nseg = 1; q.seg[0].ptr = x; q.seg[0].ld = 0; q.seg[0].nch = 3; q.Cin = 3; q.smallc = 1;
+        q.B = B; q.H = H; q.W = W;
+        q.in_sb = (int64_t)3 * H * W; q.in_sc = (int64_t)H * W; q.in_sy = W; q.in_sx = 1;
+        fill_conv_taps(q, 5, 2);
+        q.w = c->ga0.w; q.bias = c->ga0.b; q.Cout = NCH;
+        q.Ho = H / 2; q.Wo = W / 2; q.outH = q.Ho; q.outW = q.Wo; q.M = B * q.Ho * q.Wo;
+        q.out = t0; q.out_sc = 1; q.out_sx = NCH; q.out_sy = (int64_t)q.Wo * NCH; q.out_sb = (int64_t)q.Ho * q.Wo * NCH;
+        PCCHK(pc_conv_launch(q, st));
+    }
+    PCCHK(gdn(st, c->ga1, t0, B, H / 2, W / 2, false, t1));
+    PCCHK(conv(st, c->ga2, {{t1, NCH, NCH}}, B, H / 2, W / 2, 2, t2, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, c->ga3, t2, B, H / 4, W / 4, false, t3));
+    PCCHK(wam(c, st, c->ga4, t3, B, H / 4, W / 4, t2));
+    PCCHK(conv(st, c->ga5, {{t2, NCH, NCH}}, B, H / 4, W / 4, 2, t0, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, c->ga6, t0, B, H / 8, W / 8, false, t1));
+    PCCHK(conv(st, c->ga7, {{t1, NCH, NCH}}, B, H / 8, W / 8, 2, t4, MLAT, PC_EPI_NONE));
+    PCCHK(wam(c, st, c->ga8, t4, B, H / 16, W / 16, y));
+    return PC_OK;
+}
+
+// g_s[k] (CHProg_cnn.py:149-161): y_hat [B][h][w][320] -> x_hat NCHW [B][3][16h][16w], clamped to [0,1]
+int g_s(pc_codec* c, hipStream_t st, const GsW& g, const float* yhat, int B, int h, int w, float* x_hat)
+{
+    float *t0, *t1, *t2;
+    PCCHK(c->buf("gs_t0", (size_t)B * h * w * D0, &t0));
+    PCCHK(c->buf("gs_t1", (size_t)B * (8 * h) * (8 * w) * NCH, &t1));
+    PCCHK(c->buf("gs_t2", (size_t)B * (8 * h) * (8 * w) * NCH, &t2));
+    PCCHK(wam(c, st, g.w0, yhat, B, h, w, t0));
+    PCCHK(conv(st, g.d1, {{t0, D0, D0}}, B, h, w, 1, t1, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, g.g2, t1, B, 2 * h, 2 * w, true, t2));
+    PCCHK(conv(st, g.d3, {{t2, NCH, NCH}}, B, 2 * h, 2 * w, 1, t1, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, g.g4, t1, B, 4 * h, 4 * w, true, t2));
+    PCCHK(wam(c, st, g.w5, t2, B, 4 * h, 4 * w, t1));
+    PCCHK(conv(st, g.d6, {{t1, NCH, NCH}}, B, 4 * h, 4 * w, 1, t2, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, g.g7, t2, B, 8 * h, 8 * w, true, t1));
+    {   // deconv 192 -> 3, output written NCHW with clamp
+        pc_conv_params q;
+        std::memset(&q, 0, sizeof(q));
+        const int H = 8 * h, W = 8 * w;
+        q.nseg = 1; q.seg[0].ptr = t1; q.seg[0].ld = NCH; q.seg[0].nch = NCH; q.Cin = NCH;
+        q.B = B; q.H = H; q.W = W;
+        fill_deconv_taps(q);
+        q.w = g.d8.w; q.bias = g.d8.b; q.Cout = 3;
+        q.Ho = H; q.Wo = W; q.outH = 2 * H; q.outW = 2 * W; q.M = B * H * W;
+        q.out = x_hat; q.out_sx = 1; q.out_sy = q.outW; q.out_sc = (int64_t)q.outH * q.outW; q.out_sb = 3 * q.out_sc;
+        q.epi = PC_EPI_CLAMP01;
+        PCCHK(pc_conv_launch(q, st));
+    }
+    return PC_OK;
+}
+
+int h_a(pc_codec* c, hipStream_t st, const float* y, int B, int h, int w, float* z)
+{
+    float *t0, *t1;
+    PCCHK(c->buf("ha_t0", (size_t)B * h * w * 320, &t0));
+    PCCHK(c->buf("ha_t1", (size_t)B * h * w * 288, &t1));
+    PCCHK(conv(st, c->ha[0], {{y, MLAT, MLAT}}, B, h, w, 1, t0, 320, PC_EPI_GELU));
+    PCCHK(conv(st, c->ha[1], {{t0, 320, 320}}, B, h, w, 1, t1, 288, PC_EPI_GELU));
+    PCCHK(conv(st, c->ha[2], {{t1, 288, 288}}, B, h, w, 2, t0, 256, PC_EPI_GELU));
+    PCCHK(conv(st, c->ha[3], {{t0, 256, 256}}, B, h / 2, w / 2, 1, t1, 224, PC_EPI_GELU));
+    PCCHK(conv(st, c->ha[4], {{t1, 224, 224}}, B, h / 2, w / 2, 2, z, NCH, PC_EPI_NONE));
+    return PC_OK;
+}
+
+int ensure_host_staging(pc_codec* c, size_t n_int32)
+{
+    if (c->h_cap >= n_int32) return PC_OK;
+    if (c->h_sym) (void)hipHostFree(c->h_sym);
+    if (c->h_idx) (void)hipHostFree(c->h_idx);
+    c->h_sym = c->h_idx = nullptr; c->h_cap = 0;
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_sym), n_int32 * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&c->h_idx), n_int32 * 4, hipHostMallocDefault));
+    c->h_cap = n_int32;
+    return PC_OK;
+}
+
+int mask_mode_for(int mask_pol, double quality, float* q_out)
+{
+    // layers/masking.py:205-228
+    if (mask_pol == PC_MASK_TWO_LEVELS) return quality == 0 ? 3 : 2;
+    if (quality >= 10) return 2;
+    if (quality == 0) return 3;
+    const double pr = quality * 0.1;          // :212
+    *q_out = (float)(1.0 - pr);               // :213, converted to the tensor dtype by torch.quantile
+    return 1;
+}
+
+int hyper(pc_codec* c, hipStream_t st, const float* z_hat, int B, int zh, int zw, double quality, float* lm, float* ls)
+{
+    PCCHK(hs(c, st, c->hss[0], z_hat, B, zh, zw, ls, MLAT));
+    PCCHK(hs(c, st, c->hms[0], z_hat, B, zh, zw, lm, MLAT));
+    if (quality != 0) {                       // CHProg_cnn.py:708-715
+        PCCHK(hs(c, st, c->hss[1], z_hat, B, zh, zw, ls + D0, MLAT));
+        PCCHK(hs(c, st, c->hms[1], z_hat, B, zh, zw, lm + D0, MLAT));
+    }
+    return PC_OK;
+}
+
+}  // namespace
+
+// ============================================================================================== C ABI
+extern "C" int pc_pack_conv_weight(const float* w, int kind, int Cout, int Cin, int k, float* out)
+{
+    if (!w || !out || Cout <= 0 || Cin <= 0 || k <= 0) return PC_ERR_ARG;
+    // -> [ky*k+kx][Cin][Cout]
+    for (int ky = 0; ky < k; ++ky)
+        for (int kx = 0; kx < k; ++kx)
+            for (int ci = 0; ci < Cin; ++ci) {
+                float* dst = out + (((size_t)(ky * k + kx) * Cin) + ci) * Cout;
+                if (kind == 0) for (int co = 0; co < Cout; ++co) dst[co] = w[(((size_t)co * Cin + ci) * k + ky) * k + kx];
+                else for (int co = 0; co < Cout; ++co) dst[co] = w[(((size_t)ci * Cout + co) * k + ky) * k + kx];
+            }
+    return PC_OK;
+}
+
+extern "C" int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, const float* w_packed, const float* bias,
+                              int kind, int Cout, int k, int stride, int act, int tile_cfg, float* out, void* stream)
+{
+    if (!x || !w_packed || !out) return PC_ERR_ARG;
+    pc_conv_params q;
+    std::memset(&q, 0, sizeof(q));
+    q.nseg = 1; q.seg[0].ptr = x; q.seg[0].ld = Cin; q.seg[0].nch = Cin; q.Cin = Cin;
+    q.B = B; q.H = H; q.W = W;
+    if (Cin % 16) { q.smallc = 1; q.in_sc = 1; q.in_sx = Cin; q.in_sy = (int64_t)W * Cin; q.in_sb = (int64_t)H * W * Cin; if (kind != 0) return PC_ERR_ARG; }
+    q.w = w_packed; q.bias = bias; q.Cout = Cout; q.epi = act ? PC_EPI_GELU : PC_EPI_NONE; q.tile_cfg = tile_cfg;
+    if (kind == 0) {
+        fill_conv_taps(q, k, stride);
+        q.Ho = (H + 2 * (k / 2) - k) / stride + 1; q.Wo = (W + 2 * (k / 2) - k) / stride + 1; q.outH = q.Ho; q.outW = q.Wo;
+    } else {
+        if (k != 5) return PC_ERR_ARG;
+        fill_deconv_taps(q);
+        q.Ho = H; q.Wo = W; q.outH = 2 * H; q.outW = 2 * W;
+    }
+    q.M = B * q.Ho * q.Wo;
+    q.out = out; q.out_sc = 1; q.out_sx = Cout; q.out_sy = (int64_t)q.outW * Cout; q.out_sb = (int64_t)q.outH * q.outW * Cout;
+    return pc_conv_launch(q, (hipStream_t)stream);
+}
+
+extern "C" int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma_t, int inverse,
+                           float* out, void* stream)
+{
+    if (!x || !beta || !gamma_t || !out || C % 16) return PC_ERR_ARG;
+    GdnW g; g.beta = const_cast<float*>(beta); g.gamma_t = const_cast<float*>(gamma_t); g.C = C;
+    return gdn((hipStream_t)stream, g, x, B, H, W, inverse != 0, out);
+}
+
+extern "C" int pc_win_attention_nhwc(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int window,
+                                     int shift, float* out, void* stream)
+{
+    if (!qkv || !bias || !out || heads <= 0) return PC_ERR_ARG;
+    return pc_win_attention_launch(qkv, bias, B, H, W, C, heads, window, shift, 1.0f / std::sqrt((float)(C / heads)), out,
+                                   (hipStream_t)stream);
+}
+
+extern "C" int pc_mask_quantile_threshold(const float* scale, int ld, int B, int HW, int C, float q, float* thr, void* stream)
+{
+    if (!scale || !thr) return PC_ERR_ARG;
+    return pc_quantile_thr_launch(scale, ld, B, HW, C, q, thr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, const float* y, int ld_y,
+                                 const float* ybase, int ld_ybase, const float* thr, int mask_mode, int B, int HW,
+                                 const float* scale_table, int n_table, float scale_bound,
+                                 int32_t* sym, int32_t* idx, float* mask, float* yhat, int ld_yhat, void* stream)
+{
+    if (!scale || !mu || !y || !sym || !idx || !yhat || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
+    pc_prep_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.B = B; p.HW = HW; p.C = 32;
+    p.scale = scale; p.ld_scale = ld_scale; p.mu = mu; p.ld_mu = ld_mu; p.y = y; p.ld_y = ld_y;
+    p.ybase = ybase; p.ld_ybase = ld_ybase; p.thr = thr; p.mask_mode = mask_mode;
+    p.table = scale_table; p.ntable = n_table; p.bound = scale_bound;
+    p.sym = sym; p.idx = idx; p.mask = mask; p.yhat = yhat; p.ld_yhat = ld_yhat;
+    return pc_prep_enc_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int pc_gc_prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW,
+                                       const float* scale_table, int n_table, float scale_bound, int32_t* idx, float* mask,
+                                       void* stream)
+{
+    if (!scale || !idx || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
+    pc_prep_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.B = B; p.HW = HW; p.C = 32; p.scale = scale; p.ld_scale = ld_scale; p.thr = thr; p.mask_mode = mask_mode;
+    p.table = scale_table; p.ntable = n_table; p.bound = scale_bound; p.idx = idx; p.mask = mask;
+    return pc_prep_dec_index_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int pc_gc_dequantize(const int32_t* sym, const float* mu, int ld_mu, int B, int HW, float* yhat, int ld_yhat, void* stream)
+{
+    if (!sym || !mu || !yhat) return PC_ERR_ARG;
+    pc_prep_params p;
+    std::memset(&p, 0, sizeof(p));
+    p.B = B; p.HW = HW; p.C = 32; p.sym = const_cast<int32_t*>(sym); p.mu = mu; p.ld_mu = ld_mu; p.yhat = yhat; p.ld_yhat = ld_yhat;
+    return pc_prep_dec_dequant_launch(p, (hipStream_t)stream);
+}
+
+extern "C" int pc_codec_create(pc_codec** out, int device)
+{
+    if (!out) return PC_ERR_ARG;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) { g_last_hip = (int)e; return PC_ERR_HIP; }   // no GPU: fail loudly, there is no CPU fallback
+    if (device < 0 || device >= n) return PC_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    pc_codec* c = new (std::nothrow) pc_codec;
+    if (!c) return PC_ERR_NOMEM;
+    c->device = device;
+    *out = c;
+    return PC_OK;
+}
+
+extern "C" void pc_codec_destroy(pc_codec* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (void* p : c->weight_allocs) (void)hipFree(p);
+    for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (c->h_sym) (void)hipHostFree(c->h_sym);
+    if (c->h_idx) (void)hipHostFree(c->h_idx);
+    delete c;
+}
+
+extern "C" int pc_codec_set_tensor(pc_codec* c, const char* name, const void* data, int dtype, const int64_t* shape, int ndim)
+{
+    if (!c || !name || (!data && ndim) || ndim < 0 || ndim > 8) return PC_ERR_ARG;
+    if (c->finalized) return PC_ERR_STATE;
+    size_t n = 1;
+    HostTensor t;
+    for (int i = 0; i < ndim; ++i) { if (shape[i] < 0) return PC_ERR_ARG; n *= (size_t)shape[i]; t.shape.push_back(shape[i]); }
+    const size_t es = dtype == PC_I64 ? 8 : 4;
+    t.dtype = dtype;
+    t.data.assign(reinterpret_cast<const uint8_t*>(data), reinterpret_cast<const uint8_t*>(data) + n * es);
+    c->sd[name] = std::move(t);
+    return PC_OK;
+}
+
+extern "C" int pc_codec_set_tables(pc_codec* c, int which, const int32_t* cdf, int n_cdf, int cdf_stride, const int32_t* sizes,
+                                   const int32_t* offsets)
+{
+    if (!c || !cdf || !sizes || !offsets || n_cdf <= 0 || cdf_stride < 2 || which < 0 || which > 1) return PC_ERR_ARG;
+    for (int i = 0; i < n_cdf; ++i) {          // rans_interface.cpp:48-57 (assert_cdfs), enforced here
+        const int32_t* row = cdf + (size_t)i * cdf_stride;
+        if (sizes[i] < 2 || sizes[i] > cdf_stride || row[0] != 0 || row[sizes[i] - 1] != (1 << 16)) return PC_ERR_CDF;
+        for (int j = 0; j + 1 < sizes[i]; ++j) if (row[j + 1] <= row[j]) return PC_ERR_CDF;
+    }
+    Tables& t = which == 0 ? c->gc : c->eb;
+    t.cdf.assign(cdf, cdf + (size_t)n_cdf * cdf_stride);
+    t.len.assign(sizes, sizes + n_cdf);
+    t.off.assign(offsets, offsets + n_cdf);
+    t.n = n_cdf; t.stride = cdf_stride;
+    return PC_OK;
+}
+
+extern "C" int pc_codec_set_threads(pc_codec* c, int n) { if (!c) return PC_ERR_ARG; c->n_threads = n; return PC_OK; }
+
+extern "C" int pc_codec_finalize(pc_codec* c)
+{
+    if (!c) return PC_ERR_ARG;
+    if (c->finalized) return PC_OK;
+    HIPCHK(hipSetDevice(c->device));
+    PCCHK(load_conv(c, "g_a.0", 3, NCH, 5, 0, &c->ga0));
+    PCCHK(load_gdn(c, "g_a.1", NCH, &c->ga1));
+    PCCHK(load_conv(c, "g_a.2", NCH, NCH, 5, 0, &c->ga2));
+    PCCHK(load_gdn(c, "g_a.3", NCH, &c->ga3));
+    PCCHK(load_wam(c, "g_a.4", NCH, 8, 4, &c->ga4));
+    PCCHK(load_conv(c, "g_a.5", NCH, NCH, 5, 0, &c->ga5));
+    PCCHK(load_gdn(c, "g_a.6", NCH, &c->ga6));
+    PCCHK(load_conv(c, "g_a.7", NCH, MLAT, 5, 0, &c->ga7));
+    PCCHK(load_wam(c, "g_a.8", MLAT, 4, 2, &c->ga8));
+    for (int k = 0; k < 2; ++k) {
+        const std::string p = "g_s." + std::to_string(k);
+        GsW& g = c->gs[k];
+        PCCHK(load_wam(c, p + ".0", D0, 4, 2, &g.w0));
+        PCCHK(load_conv(c, p + ".1", D0, NCH, 5, 1, &g.d1));
+        PCCHK(load_gdn(c, p + ".2", NCH, &g.g2));
+        PCCHK(load_conv(c, p + ".3", NCH, NCH, 5, 1, &g.d3));
+        PCCHK(load_gdn(c, p + ".4", NCH, &g.g4));
+        PCCHK(load_wam(c, p + ".5", NCH, 8, 4, &g.w5));
+        PCCHK(load_conv(c, p + ".6", NCH, NCH, 5, 1, &g.d6));
+        PCCHK(load_gdn(c, p + ".7", NCH, &g.g7));
+        PCCHK(load_conv(c, p + ".8", NCH, 3, 5, 1, &g.d8));
+    }
+    const int ha_c[6] = {MLAT, 320, 288, 256, 224, NCH};
+    for (int j = 0; j < 5; ++j) PCCHK(load_conv(c, "h_a." + std::to_string(2 * j), ha_c[j], ha_c[j + 1], 3, 0, &c->ha[j]));
+    for (int k = 0; k < 2; ++k) {
+        PCCHK(load_hs(c, "h_mean_s." + std::to_string(k), &c->hms[k]));
+        PCCHK(load_hs(c, "h_scale_s." + std::to_string(k), &c->hss[k]));
+    }
+    for (int i = 0; i < NS0; ++i) {
+        const std::string s = "." + std::to_string(i);
+        PCCHK(load_stack5(c, "cc_mean_transforms" + s, D0 + 32 * std::min(i, 5), &c->cc_mean[i]));
+        PCCHK(load_stack5(c, "cc_scale_transforms" + s, D0 + 32 * std::min(i, 5), &c->cc_scale[i]));
+        PCCHK(load_stack5(c, "lrp_transforms" + s, D0 + 32 * std::min(i + 1, 6), &c->lrp[i]));
+        PCCHK(load_stack5(c, "cc_mean_transforms_prog" + s, D0 + 32 * std::min(i + 1, 6), &c->cc_mean_p[i]));
+        PCCHK(load_stack5(c, "cc_scale_transforms_prog" + s, D0 + 32 * std::min(i + 1, 6), &c->cc_scale_p[i]));
+        PCCHK(load_stack5(c, "lrp_transforms_prog" + s, D0 + 32 * std::min(i + 2, 7), &c->lrp_p[i]));
+    }
+    {   // EntropyBottleneck medians = quantiles[:, 0, 1]  (entropy_models.py:350)
+        const HostTensor* q = find(c, "entropy_bottleneck.quantiles", PC_F32, {NCH, 1, 3});
+        if (!q) return PC_ERR_MISSING;
+        std::vector<float> med(NCH);
+        for (int i = 0; i < NCH; ++i) med[i] = reinterpret_cast<const float*>(q->data.data())[3 * i + 1];
+        PCCHK(upload(c, med, &c->medians));
+    }
+    {   // scale table from the module buffer (never recomputed), LowerBound from its buffer
+        auto it = c->sd.find("gaussian_conditional.scale_table");
+        if (it == c->sd.end() || it->second.dtype != PC_F32 || it->second.shape.size() != 1 || it->second.shape[0] < 2 || it->second.shape[0] > 64) return PC_ERR_MISSING;
+        c->n_table = (int)it->second.shape[0];
+        std::vector<float> tab(reinterpret_cast<const float*>(it->second.data.data()), reinterpret_cast<const float*>(it->second.data.data()) + c->n_table);
+        PCCHK(upload(c, tab, &c->scale_table));
+        const HostTensor* b = find(c, "gaussian_conditional.lower_bound_scale.bound", PC_F32, {1});
+        if (!b) return PC_ERR_MISSING;
+        c->scale_bound = reinterpret_cast<const float*>(b->data.data())[0];
+    }
+    c->sd.clear();
+    c->finalized = true;
+    return PC_OK;
+}
+
+extern "C" int pc_codec_num_slices(const pc_codec* c) { return c ? c->res_slices : 0; }
+
+extern "C" int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len)
+{
+    if (!c || !data || !len || b < 0 || b >= c->res_B) return PC_ERR_ARG;
+    const std::vector<uint8_t>* s;
+    if (slice == -1) s = &c->z_strings[b];
+    else if (slice >= 0 && slice < c->res_slices) s = &c->y_strings[(size_t)slice * c->res_B + b];
+    else return PC_ERR_ARG;
+    *data = s->data(); *len = s->size();
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- compress
+extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
+                                 float* masks_out, void* stream)
+{
+    if (!c || !x || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
+    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (!c->finalized || !c->gc.ok() || !c->eb.ok()) return PC_ERR_STATE;
+    if (c->eb.n != NCH) return PC_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
+    const size_t M = (size_t)B * HW;
+    const int n_slices = quality <= 0 ? NS0 : 2 * NS0;
+    c->last_B = B; c->last_h16 = h; c->last_w16 = w;
+
+    float *y, *z, *z_hat, *lm, *ls, *yb, *ye, *mu, *scale, *thr;
+    int32_t *z_sym, *sym, *idx;
+    PCCHK(c->buf("y", M * MLAT, &y));
+    PCCHK(c->buf("z", (size_t)B * ZHW * NCH, &z));
+    PCCHK(c->buf("z_hat", (size_t)B * ZHW * NCH, &z_hat));
+    PCCHK(c->buf("z_sym", (size_t)B * ZHW * NCH, &z_sym));
+    PCCHK(c->buf("latent_means", M * MLAT, &lm));
+    PCCHK(c->buf("latent_scales", M * MLAT, &ls));
+    PCCHK(c->buf("yhat_base", M * D0, &yb));
+    PCCHK(c->buf("yhat_enh", M * D0, &ye));
+    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &mu));            // per-slice mu / scale kept for taps
+    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &scale));
+    PCCHK(c->buf("thr", (size_t)B * NS0, &thr));
+    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &sym));
+    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &idx));
+
+    PCCHK(g_a(c, st, x, B, H, W, y));                                                    // :692
+    PCCHK(h_a(c, st, y, B, h, w, z));                                                    // :700
+    PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :702-704
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, lm, ls));                              // :705-715
+
+    for (int i = 0; i < NS0; ++i) {                                                      // base slices, :729-764
+        const int ns = std::min(5, i);
+        float* mu_i = mu + (size_t)i * M * SLICE;
+        float* sc_i = scale + (size_t)i * M * SLICE;
+        PCCHK(stack5(c, st, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
+        PCCHK(stack5(c, st, c->cc_scale[i], {{ls, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
+        PCCHK(pc_gc_prep_encode(sc_i, SLICE, mu_i, SLICE, y + 32 * i, MLAT, nullptr, 0, nullptr, 0, B, HW,
+                                c->scale_table, c->n_table, c->scale_bound,
+                                sym + (size_t)i * M * SLICE, idx + (size_t)i * M * SLICE, nullptr, yb + 32 * i, D0, st));
+        if (i < 5)
+            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 32 * (i + 1)}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
+        else
+            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 160}, {yb + 32 * i, D0, 32}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
+    }
+    if (n_slices > NS0) {
+        float q = 0.0f;
+        const int mode = mask_mode_for(mask_pol, quality, &q);
+        for (int i = 0; i < NS0; ++i) {                                                  // enhancement slices, :775-845
+            const int s = std::min(5, i);
+            float* mu_i = mu + (size_t)(NS0 + i) * M * SLICE;
+            float* sc_i = scale + (size_t)(NS0 + i) * M * SLICE;
+            PCCHK(stack5(c, st, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
+            PCCHK(stack5(c, st, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
+            if (mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, B, HW, SLICE, q, thr + (size_t)i * B, nullptr, st));   // :819-824
+            PCCHK(pc_gc_prep_encode(sc_i, SLICE, mu_i, SLICE, y + 32 * (NS0 + i), MLAT, y + 32 * i, MLAT, thr + (size_t)i * B, mode, B, HW,
+                                    c->scale_table, c->n_table, c->scale_bound,
+                                    sym + (size_t)(NS0 + i) * M * SLICE, idx + (size_t)(NS0 + i) * M * SLICE,
+                                    masks_out ? masks_out + (size_t)i * M * SLICE : nullptr, ye + 32 * i, D0, st));
+            PCCHK(stack5(c, st, c->lrp_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * (s + 1)}}, B, h, w,
+                         ye + 32 * i, D0, PC_EPI_LRP_ADD, ye + 32 * i, D0, yb + 32 * i, D0, "s5m"));
+        }
+    }
+    // ---- symbols/indexes to the host, rANS on the thread pool  (entropy_models.py:226-235)
+    const size_t n_y = (size_t)n_slices * M * SLICE, n_z = (size_t)B * ZHW * NCH;
+    PCCHK(ensure_host_staging(c, n_y + n_z));
+    HIPCHK(hipMemcpyAsync(c->h_sym, sym, n_y * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_idx, idx, n_y * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_sym + n_y, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (size_t e = 0; e < n_z; ++e) c->h_idx[n_y + e] = (int32_t)((e / ZHW) % NCH);     // EntropyBottleneck._build_indexes :492-502
+    c->res_slices = n_slices; c->res_B = B;
+    c->y_strings.assign((size_t)n_slices * B, {});
+    c->z_strings.assign(B, {});
+    const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
+    std::atomic<int> rc{PC_OK};
+    auto job = [&](size_t j) {
+        const bool is_z = j >= (size_t)n_slices * B;
+        const size_t n = is_z ? per_z : per;
+        const size_t off = is_z ? n_y + (j - (size_t)n_slices * B) * per_z : j * per;
+        const Tables& t = is_z ? c->eb : c->gc;
+        std::vector<uint8_t>& dst = is_z ? c->z_strings[j - (size_t)n_slices * B] : c->y_strings[j];
+        dst.resize(pc_rans_bound(n));
+        size_t len = 0;
+        const int r = pc_rans_encode_with_indexes(c->h_sym + off, c->h_idx + off, n, t.cdf.data(), t.n, t.stride, t.len.data(),
+                                                  t.off.data(), dst.data(), dst.size(), &len);
+        if (r != PC_OK) rc = r;
+        dst.resize(len);
+    };
+    const size_t n_jobs = (size_t)n_slices * B + B;
+    if (c->n_threads == 1) for (size_t j = 0; j < n_jobs; ++j) job(j);
+    else pc::default_pool().parallel_for(n_jobs, job);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- decompress
+extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens, int n_slices,
+                                   const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
+                                   double quality, int mask_pol, float* x_hat, void* stream)
+{
+    if (!c || !y_strings || !y_lens || !z_strings || !z_lens || !x_hat || B <= 0 || zh <= 0 || zw <= 0) return PC_ERR_ARG;
+    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (n_slices < (quality == 0 ? NS0 : 2 * NS0)) return PC_ERR_ARG;
+    if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int h = 4 * zh, w = 4 * zw, HW = h * w, ZHW = zh * zw;
+    const size_t M = (size_t)B * HW;
+    c->last_B = B; c->last_h16 = h; c->last_w16 = w;
+
+    float *z_hat, *lm, *ls, *yb, *ye, *mu, *scale, *thr;
+    int32_t *z_sym, *sym, *idx;
+    PCCHK(c->buf("z_hat", (size_t)B * ZHW * NCH, &z_hat));
+    PCCHK(c->buf("z_sym", (size_t)B * ZHW * NCH, &z_sym));
+    PCCHK(c->buf("latent_means", M * MLAT, &lm));
+    PCCHK(c->buf("latent_scales", M * MLAT, &ls));
+    PCCHK(c->buf("yhat_base", M * D0, &yb));
+    PCCHK(c->buf("yhat_enh", M * D0, &ye));
+    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &mu));
+    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &scale));
+    PCCHK(c->buf("thr", (size_t)B * NS0, &thr));
+    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &sym));
+    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &idx));
+    const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
+    PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
+    const int nt = c->n_threads == 1 ? 1 : 0;
+
+    // z: host rANS decode -> device dequantise   (:855)
+    for (size_t e = 0; e < per_z * B; ++e) c->h_idx[e] = (int32_t)((e / ZHW) % NCH);
+    PCCHK(pc_rans_decode_batch(z_strings, z_lens, B, c->h_idx, per_z, c->eb.cdf.data(), c->eb.n, c->eb.stride, c->eb.len.data(),
+                               c->eb.off.data(), c->h_sym, nt));
+    HIPCHK(hipMemcpyAsync(z_sym, c->h_sym, per_z * B * 4, hipMemcpyHostToDevice, st));
+    PCCHK(pc_eb_dequant_launch(z_sym, B, ZHW, NCH, c->medians, z_hat, st));
+    HIPCHK(hipStreamSynchronize(st));   // h_sym is reused below
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, lm, ls));                              // :856-867
+
+    auto decode_slice = [&](int slice, const float* sc_i, const float* mu_i, const float* thr_i, int mode, float* yhat_dst) -> int {
+        int32_t* idx_i = idx + (size_t)slice * M * SLICE;
+        int32_t* sym_i = sym + (size_t)slice * M * SLICE;
+        PCCHK(pc_gc_prep_decode_index(sc_i, SLICE, thr_i, mode, B, HW, c->scale_table, c->n_table, c->scale_bound, idx_i, nullptr, st));
+        HIPCHK(hipMemcpyAsync(c->h_idx, idx_i, per * B * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        PCCHK(pc_rans_decode_batch(y_strings + (size_t)slice * B, y_lens + (size_t)slice * B, B, c->h_idx, per, c->gc.cdf.data(), c->gc.n,
+                                   c->gc.stride, c->gc.len.data(), c->gc.off.data(), c->h_sym, nt));
+        HIPCHK(hipMemcpyAsync(sym_i, c->h_sym, per * B * 4, hipMemcpyHostToDevice, st));
+        PCCHK(pc_gc_dequantize(sym_i, mu_i, SLICE, B, HW, yhat_dst, D0, st));
+        HIPCHK(hipStreamSynchronize(st));   // staging buffer reuse
+        return PC_OK;
+    };
+
+    for (int i = 0; i < NS0; ++i) {                                                      // :874-904
+        const int ns = std::min(5, i);
+        float* mu_i = mu + (size_t)i * M * SLICE;
+        float* sc_i = scale + (size_t)i * M * SLICE;
+        PCCHK(stack5(c, st, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
+        PCCHK(stack5(c, st, c->cc_scale[i], {{ls, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
+        PCCHK(decode_slice(i, sc_i, mu_i, nullptr, 0, yb + 32 * i));
+        if (i < 5)
+            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 32 * (i + 1)}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
+        else
+            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 160}, {yb + 32 * i, D0, 32}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
+    }
+    if (quality == 0) {                                                                  // :907-916
+        PCCHK(g_s(c, st, c->gs[0], yb, B, h, w, x_hat));
+        return PC_OK;
+    }
+    float q = 0.0f;
+    const int mode = mask_mode_for(mask_pol, quality, &q);
+    for (int i = 0; i < NS0; ++i) {                                                      // :921-983
+        const int s = std::min(5, i);
+        float* mu_i = mu + (size_t)(NS0 + i) * M * SLICE;
+        float* sc_i = scale + (size_t)(NS0 + i) * M * SLICE;
+        PCCHK(stack5(c, st, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
+        PCCHK(stack5(c, st, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
+        if (mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, B, HW, SLICE, q, thr + (size_t)i * B, nullptr, st));
+        PCCHK(decode_slice(NS0 + i, sc_i, mu_i, thr + (size_t)i * B, mode, ye + 32 * i));
+        PCCHK(stack5(c, st, c->lrp_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * (s + 1)}}, B, h, w,
+                     ye + 32 * i, D0, PC_EPI_LRP_ADD, ye + 32 * i, D0, yb + 32 * i, D0, "s5m"));
+    }
+    PCCHK(g_s(c, st, c->gs[1], ye, B, h, w, x_hat));                                     // :986-990
+    return PC_OK;
+}
+
+extern "C" int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap, size_t* n)
+{
+    if (!c || !name || !n) return PC_ERR_ARG;
+    auto it = c->bufs.find(name);
+    if (it == c->bufs.end()) return PC_ERR_ARG;
+    const size_t cnt = it->second.bytes / 4;
+    *n = cnt;
+    if (!host_out) return PC_OK;
+    const size_t m = std::min(cnt, cap);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(host_out, it->second.p, m * 4, hipMemcpyDeviceToHost));
+    return PC_OK;
+}
+
+extern "C" int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* host_out, size_t cap, size_t* n)
+{
+    return pc_codec_read_tap(c, name, reinterpret_cast<float*>(host_out), cap, n);
+}

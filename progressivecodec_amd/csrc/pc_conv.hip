@@ -1,0 +1,301 @@
+// pc_conv.hip -- tap-list implicit-GEMM convolution on the gfx950 f32 MFMA pipe.
+//
+// One kernel family serves every dense contraction of the codec (reference modules in
+// /root/reference/src/compress): nn.Conv2d 5x5 s2 (models/utils.py:186), conv3x3 s1/s2
+// and conv1x1 (layers/layers.py:15,27), nn.Linear qkv/proj (layers/win_attention.py:76,78),
+// the GDN/IGDN 1x1 contraction over x^2 (layers/gdn.py:56), sub-pixel conv with
+// PixelShuffle folded into the store (layers/layers.py:20-24) and the four output phases
+// of ConvTranspose2d(5, s2, p2, op1) (models/utils.py:196).
+//
+//   out[b, i*osy+ooy, j*osx+oox, n] = epi( bias[n] + sum_{t<T} sum_{c<Cin} f(in[b, i*s+dy_t, j*s+dx_t, c]) * w[wtap_t][c][n] )
+//
+// GEMM view: M = B*Ho*Wo output pixels, N = Cout, K = T*Cin.  Activations are NHWC so a
+// K-chunk (one tap x 16 channels) is 64 contiguous bytes per pixel; the channel axis of the
+// input may be a *virtual concatenation* of up to 8 segments (no torch.cat copies in the
+// 20-step slice chain).  Numeric contract (include/pc_math.h): each output
+// element is ONE fmaf chain over (tap, channel) ascending starting at +0 -- exactly what
+// v_mfma_f32_32x32x2_f32 computes when the K loop feeds it in order and nothing is split
+// along K -- so results are bit-identical for every tile shape, batch size and device, and
+// equal to oracle/pc_oracle.c:orc_conv_nhwc.
+//
+// Tiling: 256 threads = 4 waves (64 lanes); block tile BM x BN; K-chunk 16; each wave owns
+// TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); A/B chunks are register-staged
+// global->LDS with double buffering (one barrier per chunk); LDS images are k-major
+// ([k][m] / [k][n]) so every ds_read_b32 of an MFMA operand is bank-conflict-free.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pc_math.h"
+#include "pc_device.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+__device__ __forceinline__ float epilogue_value(const pc_conv_params& p, float v, int64_t pix, int n)
+{
+    switch (p.epi) {
+    case PC_EPI_NONE: return v;
+    case PC_EPI_GELU: return pc_geluf(v);
+    case PC_EPI_RES_GELU: return pc_geluf(v + p.aux0[pix * p.ld0 + n]);
+    case PC_EPI_RES: return p.aux0[pix * p.ld0 + n] + v;
+    case PC_EPI_GATE: return p.aux0[pix * p.ld0 + n] * pc_sigmoidf(v) + p.aux1[pix * p.ld1 + n];
+    case PC_EPI_GDN: return p.aux0[pix * p.ld0 + n] * pc_rsqrtf(v);
+    case PC_EPI_IGDN: return p.aux0[pix * p.ld0 + n] * sqrtf(v);
+    case PC_EPI_CLAMP01: return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    case PC_EPI_LRP: return p.aux0[pix * p.ld0 + n] + 0.5f * pc_tanhf(v);
+    case PC_EPI_LRP_ADD: return (p.aux0[pix * p.ld0 + n] + 0.5f * pc_tanhf(v)) + p.aux1[pix * p.ld1 + n];
+    default: return v;
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALLC>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
+{
+    constexpr int BK = 16;
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int LDA = BM + 4, LDB = BN + 4;
+    constexpr int AI = (BM * 4 + 255) / 256;          // float4 A loads per thread per chunk
+    constexpr int BI = (BN * 4 + 255) / 256;          // float4 B loads per thread per chunk
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    __shared__ float smem[2 * BK * (LDA + LDB)];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int phase = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int T = p.ntap[phase];
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- per-thread A rows (fixed over the K loop)
+    int a_row[AI], a_iy0[AI], a_ix0[AI];
+    int64_t a_boff[AI];
+    bool a_ok[AI];
+    const int kq = tid & 3;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = (tid >> 2) + i * 64;
+        a_row[i] = row;
+        const int m = m0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / HoWo, r = mm - b * HoWo;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_iy0[i] = oy * p.stride;
+        a_ix0[i] = ox * p.stride;
+        a_boff[i] = (int64_t)b * p.H * p.W;
+    }
+    // ---- per-thread B positions
+    constexpr int BQ = BN / 4;                         // float4 per B row
+    int b_k[BI], b_n[BI];
+    bool b_ok[BI];
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+        const int e = tid + i * 256;
+        b_k[i] = e / BQ;
+        b_n[i] = (e % BQ) * 4;
+        b_ok[i] = (b_k[i] < BK) && (n0 + b_n[i] < p.Cout);   // Cout % 4 == 0 except the N=3 layer (handled per element)
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // ---- chunk iterator state (uniform): tap t, segment s, channel c within segment, global channel cg
+    int it_t = 0, it_s = 0, it_c = 0, it_cg = 0;
+    int nchunks;
+    if (SMALLC) nchunks = (T * p.Cin + BK - 1) / BK;
+    else nchunks = T * (p.Cin / BK);
+
+    float4 ra[AI], rb[BI];
+
+    auto load_chunk = [&](int chunk) {
+        if (SMALLC) {
+            // flattened k = t*Cin + c; element-wise gather with generic input strides (NCHW image input)
+            const int Ktot = T * p.Cin;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int kf = chunk * BK + kq * 4 + j;
+                    float x = 0.0f;
+                    if (a_ok[i] && kf < Ktot) {
+                        const int t = kf / p.Cin, c = kf - t * p.Cin;
+                        const int iy = a_iy0[i] + p.dy[phase][t], ix = a_ix0[i] + p.dx[phase][t];
+                        if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) {
+                            const int64_t b = a_boff[i] / ((int64_t)p.H * p.W);
+                            x = p.seg[0].ptr[b * p.in_sb + (int64_t)iy * p.in_sy + (int64_t)ix * p.in_sx + (int64_t)c * p.in_sc];
+                        }
+                    }
+                    v[j] = x;
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                const int kf = chunk * BK + b_k[i];
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_ok[i] && kf < Ktot) {
+                    const float* wp = p.w + (int64_t)kf * p.Cout + n0 + b_n[i];   // w[t][c][n] flattened == w[kf][n] (wtap = t)
+                    if (n0 + b_n[i] + 3 < p.Cout) w = *reinterpret_cast<const float4*>(wp);
+                    else { w.x = wp[0]; if (n0 + b_n[i] + 1 < p.Cout) w.y = wp[1]; if (n0 + b_n[i] + 2 < p.Cout) w.z = wp[2]; }
+                }
+                rb[i] = w;
+            }
+        } else {
+            const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
+            const float* sp = p.seg[it_s].ptr;
+            const int sld = p.seg[it_s].ld;
+#pragma unroll
+            for (int i = 0; i < AI; ++i) {
+                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (a_ok[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                    v = *reinterpret_cast<const float4*>(sp + (a_boff[i] + (int64_t)iy * p.W + ix) * sld + it_c + kq * 4);
+                if (p.square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
+                ra[i] = v;
+            }
+            const float* wrow = p.w + ((int64_t)p.wtap[phase][it_t] * p.Cin + it_cg) * p.Cout + n0;
+#pragma unroll
+            for (int i = 0; i < BI; ++i) {
+                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (b_ok[i]) {
+                    const float* wp = wrow + (int64_t)b_k[i] * p.Cout + b_n[i];
+                    if (n0 + b_n[i] + 3 < p.Cout) w = *reinterpret_cast<const float4*>(wp);
+                    else { w.x = wp[0]; if (n0 + b_n[i] + 1 < p.Cout) w.y = wp[1]; if (n0 + b_n[i] + 2 < p.Cout) w.z = wp[2]; }
+                }
+                rb[i] = w;
+            }
+            // advance (t, seg, c)
+            it_c += BK; it_cg += BK;
+            if (it_c >= p.seg[it_s].nch) { it_c = 0; ++it_s; if (it_s >= p.nseg) { it_s = 0; it_cg = 0; ++it_t; } }
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+        float* a = As + buf * BK * LDA;
+        float* b = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            if (a_row[i] < BM) {
+                a[(kq * 4 + 0) * LDA + a_row[i]] = ra[i].x;
+                a[(kq * 4 + 1) * LDA + a_row[i]] = ra[i].y;
+                a[(kq * 4 + 2) * LDA + a_row[i]] = ra[i].z;
+                a[(kq * 4 + 3) * LDA + a_row[i]] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+            if (b_k[i] < BK) *reinterpret_cast<float4*>(b + b_k[i] * LDB + b_n[i]) = rb[i];
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    int cur = 0;
+    const int half = lane >> 5, l31 = lane & 31;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        if (chunk + 1 < nchunks) load_chunk(chunk + 1);
+        const float* a = As + cur * BK * LDA + wm * (TM * 32) + l31;
+        const float* b = Bs + cur * BK * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = a[(kk + half) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = b[(kk + half) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        if (chunk + 1 < nchunks) store_chunk(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = m0 + wm * (TM * 32) + i * 32 + row;
+            if (m >= p.M) continue;
+            const int b = m / HoWo, rr = m - b * HoWo;
+            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+            int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v = v + p.bias[n];
+                int nn = n, YY = Y, XX = X;
+                if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
+                const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
+                v = epilogue_value(p, v, pix, nn);
+                p.out[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
+{
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.nphase);
+    if (p.smallc)
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// Host-side validation + tile selection.  Returns a pc status code.
+int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
+{
+    if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
+    if (!p.smallc) {
+        int c = 0;
+        if (p.nseg < 1 || p.nseg > PC_MAX_SEG) return PC_ERR_ARG;
+        for (int s = 0; s < p.nseg; ++s) {
+            if (p.seg[s].nch <= 0 || p.seg[s].nch % 16 || p.seg[s].ld % 4 || ((uintptr_t)p.seg[s].ptr & 15)) return PC_ERR_ARG;
+            c += p.seg[s].nch;
+        }
+        if (c != p.Cin) return PC_ERR_ARG;
+        if (p.Cout % 4 && p.Cout > 4) return PC_ERR_ARG;
+    } else if (p.nseg != 1) return PC_ERR_ARG;
+    for (int ph = 0; ph < p.nphase; ++ph)
+        if (p.ntap[ph] < 1 || p.ntap[ph] > PC_MAX_TAP) return PC_ERR_ARG;
+    if (p.pixel_shuffle && (p.Cout % 4)) return PC_ERR_ARG;
+
+    int cfg = p.tile_cfg;
+    if (cfg == PC_TILE_AUTO) {
+        // heuristic: the largest tile that still yields >= 2 waves per SIMD (2048 waves), N-tail aware
+        const long tiles32 = (long)((p.M + 31) / 32) * ((p.Cout + 31) / 32) * p.nphase;
+        if (p.Cout <= 32) cfg = PC_TILE_128x32;
+        else if (tiles32 >= 4L * 2048 * 2 && p.Cout % 128 == 0) cfg = PC_TILE_128x128;
+        else if (p.Cout % 64 == 0 || p.Cout > 256) cfg = PC_TILE_64x64;
+        else cfg = PC_TILE_128x32;
+    }
+    hipError_t e;
+    switch (cfg) {
+    case PC_TILE_128x128: e = launch_cfg<128, 128, 2, 2>(p, stream); break;
+    case PC_TILE_64x64: e = launch_cfg<64, 64, 2, 2>(p, stream); break;
+    case PC_TILE_128x32: e = launch_cfg<128, 32, 4, 1>(p, stream); break;
+    default: return PC_ERR_ARG;
+    }
+    return e == hipSuccess ? PC_OK : PC_ERR_HIP;
+}

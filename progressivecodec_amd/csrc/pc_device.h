@@ -1,0 +1,100 @@
+// pc_device.h -- internal declarations shared by the HIP translation units of libpcodec.
+#ifndef PC_DEVICE_H
+#define PC_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcodec.h"
+
+#define PC_MAX_SEG 8
+#define PC_MAX_TAP 25
+
+enum {
+    PC_EPI_NONE = 0,
+    PC_EPI_GELU = 1,      // nn.GELU (erf form)
+    PC_EPI_RES_GELU = 2,  // ResidualUnit tail: gelu(conv + identity)            layers.py:51-57
+    PC_EPI_RES = 3,       // window attention: shortcut + proj(...)               win_attention.py:205
+    PC_EPI_GATE = 4,      // WAM: a * sigmoid(b) + identity                       layers.py:72-75
+    PC_EPI_GDN = 5,       // x * rsqrt(beta + gamma . x^2)                        gdn.py:56-63
+    PC_EPI_IGDN = 6,      // x * sqrt(...)
+    PC_EPI_CLAMP01 = 7,   // x_hat.clamp_(0, 1)                                   CHProg_cnn.py:909,988
+    PC_EPI_LRP = 8,       // y_hat + 0.5 * tanh(lrp)                              CHProg_cnn.py:759-762
+    PC_EPI_LRP_ADD = 9,   // (y_hat + 0.5 * tanh(lrp)) + base  (merge "res")      CHProg_cnn.py:837-843
+};
+
+enum { PC_TILE_AUTO = 0, PC_TILE_128x128 = 1, PC_TILE_64x64 = 2, PC_TILE_128x32 = 3 };
+
+struct pc_seg {
+    const float* ptr;  // first channel of this segment at pixel 0
+    int ld;            // floats between consecutive pixels
+    int nch;           // channels in this segment (multiple of 16)
+};
+
+struct pc_conv_params {
+    // input: NHWC, channel axis = concatenation of segments (all segments share B, H, W)
+    pc_seg seg[PC_MAX_SEG];
+    int nseg, Cin;
+    int B, H, W;
+    int smallc;                              // element-wise gather path (Cin not a multiple of 16); uses in_s*
+    int64_t in_sb, in_sy, in_sx, in_sc;      // generic input strides (smallc only)
+    int square;                              // feed x*x (GDN)
+    // taps per output phase
+    int nphase;
+    int ntap[4];
+    int8_t dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
+    int wtap[4][PC_MAX_TAP];                 // weight tap index
+    int stride;
+    // weights [ntaps][Cin][Cout], bias [Cout] or null
+    const float* w;
+    const float* bias;
+    int Cout;
+    // output grid per phase and mapping into the output tensor
+    int Ho, Wo, M;                           // M = B*Ho*Wo
+    int osy, osx, ooy[4], oox[4];
+    int outH, outW;
+    int64_t out_sb, out_sy, out_sx, out_sc;  // generic output strides (NHWC slice or NCHW)
+    float* out;
+    int pixel_shuffle;                       // PixelShuffle(2) folded into the store
+    // epilogue
+    int epi;
+    const float* aux0; int ld0;
+    const float* aux1; int ld1;
+    int tile_cfg;
+};
+
+int pc_conv_launch(const pc_conv_params& p, hipStream_t stream);
+
+// window attention core
+int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int ws,
+                            int shift, float scale, float* out, hipStream_t stream);
+
+// entropy-parameter stages
+struct pc_prep_params {
+    int B, HW, C;             // one slice: B images x HW pixels x C (=32) channels, NHWC inputs
+    const float* scale; int ld_scale;
+    const float* mu; int ld_mu;
+    const float* y; int ld_y;          // encoder: latent slice
+    const float* ybase; int ld_ybase;  // encoder, delta_encode: base slice to subtract (or null)
+    const float* thr;                  // per-image mask threshold (null: no mask; enhancement only)
+    int mask_mode;                     // 0 none, 1 threshold compare, 2 all ones, 3 all zeros
+    const float* table; int ntable; float bound;
+    int32_t* sym;                      // [B][C][HW]  (C,H,W raster order = rANS order)
+    int32_t* idx;                      // [B][C][HW]
+    float* mask;                       // [B][C][HW] float 0/1 or null
+    float* yhat; int ld_yhat;          // NHWC: float(sym) + mu
+};
+int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream);
+int pc_prep_dec_index_launch(const pc_prep_params& p, hipStream_t stream);   // scale(+mask) -> idx (+mask)
+int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream); // sym + mu -> yhat
+
+int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work,
+                           hipStream_t stream);
+size_t pc_quantile_work_bytes(int B);
+
+int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* medians, int32_t* sym, float* zhat,
+                       hipStream_t stream);
+int pc_eb_dequant_launch(const int32_t* sym, int B, int HW, int C, const float* medians, float* zhat,
+                         hipStream_t stream);
+
+#endif

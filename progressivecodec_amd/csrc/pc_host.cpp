@@ -1,0 +1,313 @@
+// pc_host.cpp -- host side of libpcodec: the rANS entropy coder, pmf->CDF quantiser, a small
+// thread pool for per-image streams, error strings.
+//
+// The coder reproduces the reference's byte streams exactly (cpp_exts/rans/rans_interface.cpp,
+// third_party/ryg_rans/rans64.h) but is organised differently: symbols are walked backwards and
+// encoded straight into the output words (no intermediate record vector), and the decoder finds
+// the symbol by binary search over the CDF row instead of a linear scan.
+#include <atomic>
+#include <cmath>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../include/pcodec.h"
+#include "pc_host.h"
+
+namespace {
+constexpr uint64_t kRansL = 1ull << 31;   // rans64.h:59
+constexpr int kPrecision = 16;            // rans_interface.cpp:40
+constexpr int kBypassBits = 4;            // rans_interface.cpp:42
+constexpr int kBypassMax = 15;            // rans_interface.cpp:43
+
+struct Writer {
+    uint32_t* begin;
+    uint32_t* ptr;   // grows downwards
+    bool overflow = false;
+    inline void put(uint32_t w) { if (ptr == begin) { overflow = true; return; } *--ptr = w; }
+};
+
+inline void enc_put(uint64_t& x, Writer& wr, uint32_t start, uint32_t freq)          // Rans64EncPut, rans64.h:77-93
+{
+    const uint64_t x_max = ((kRansL >> kPrecision) << 32) * freq;
+    if (x >= x_max) { wr.put((uint32_t)x); x >>= 32; }
+    x = ((x / freq) << kPrecision) + (x % freq) + start;
+}
+inline void enc_put_bits(uint64_t& x, Writer& wr, uint32_t val)                       // Rans64EncPutBits, rans_interface.cpp:60-78
+{
+    const uint32_t freq = 1u << (16 - kBypassBits);
+    const uint64_t x_max = ((kRansL >> 16) << 32) * freq;
+    if (x >= x_max) { wr.put((uint32_t)x); x >>= 32; }
+    x = (x << kBypassBits) | val;
+}
+}  // namespace
+
+extern "C" size_t pc_rans_bound(size_t n)
+{
+    // worst case per symbol: 1 table symbol (<= 16 bits... one 32-bit word at most every other put) plus
+    // bypass: count nibbles (<= 1 + 8/15 rounds) and 8 value nibbles -> well under 3 words; + 2 state words.
+    return 4 * (3 * n + 4);
+}
+
+extern "C" int pc_rans_encode_with_indexes(const int32_t* symbols, const int32_t* indexes, size_t n,
+                                           const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                           const int32_t* cdf_sizes, const int32_t* offsets,
+                                           uint8_t* out, size_t out_cap, size_t* out_len)
+{
+    if ((!symbols || !indexes) && n) return PC_ERR_ARG;
+    if (!cdfs || !cdf_sizes || !offsets || !out || !out_len || n_cdf <= 0 || cdf_stride <= 0) return PC_ERR_ARG;
+    const size_t cap_words = out_cap / 4;
+    if (cap_words < 2) return PC_ERR_BUFFER;
+    // Encode into the tail of `out` (aligned down to 4 bytes), then move to the front.
+    uint32_t* base = reinterpret_cast<uint32_t*>(out);
+    if (reinterpret_cast<uintptr_t>(out) & 3) return PC_ERR_ARG;
+    Writer wr{base, base + cap_words};
+    uint64_t x = kRansL;                                                              // Rans64EncInit
+    for (size_t ii = n; ii-- > 0;) {
+        const int32_t ci = indexes[ii];
+        if (ci < 0 || ci >= n_cdf) return PC_ERR_INDEX;
+        const int32_t len = cdf_sizes[ci];
+        if (len < 2 || len > cdf_stride) return PC_ERR_CDF;
+        const int32_t* cdf = cdfs + (size_t)ci * cdf_stride;
+        const int32_t max_value = len - 2;                                            // :115
+        int32_t value = symbols[ii] - offsets[ci];                                    // :119
+        uint32_t raw = 0;
+        bool escaped = false;
+        if (value < 0) { raw = (uint32_t)(-2 * (int64_t)value - 1); value = max_value; escaped = true; }
+        else if (value >= max_value) { raw = (uint32_t)(2 * ((int64_t)value - max_value)); value = max_value; escaped = true; }
+        if (escaped) {
+            // forward order is: symbol, count nibbles (15,15,...,rest), value nibbles (LSB first)   :138-162
+            // -> encode in exact reverse
+            int32_t n_bypass = 0;
+            while (n_bypass < 8 && (raw >> (n_bypass * kBypassBits)) != 0) ++n_bypass;
+            for (int32_t j = n_bypass - 1; j >= 0; --j) enc_put_bits(x, wr, (raw >> (j * kBypassBits)) & kBypassMax);
+            const int32_t full = n_bypass / kBypassMax, rest = n_bypass % kBypassMax;
+            enc_put_bits(x, wr, (uint32_t)rest);
+            for (int32_t j = 0; j < full; ++j) enc_put_bits(x, wr, kBypassMax);
+        }
+        const uint32_t start = (uint32_t)cdf[value], freq = (uint32_t)(cdf[value + 1] - cdf[value]);
+        if (freq == 0 || freq > 65536u) return PC_ERR_CDF;
+        enc_put(x, wr, start, freq);
+    }
+    wr.put((uint32_t)(x >> 32));                                                      // Rans64EncFlush, rans64.h:96-103
+    wr.put((uint32_t)x);
+    if (wr.overflow) return PC_ERR_BUFFER;
+    const size_t nwords = (size_t)((base + cap_words) - wr.ptr);
+    std::memmove(out, wr.ptr, nwords * 4);
+    *out_len = nwords * 4;
+    return PC_OK;
+}
+
+extern "C" int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encoded_len,
+                                           const int32_t* indexes, size_t n,
+                                           const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                           const int32_t* cdf_sizes, const int32_t* offsets,
+                                           int32_t* out)
+{
+    if (!encoded || (!indexes && n) || !cdfs || !cdf_sizes || !offsets || (!out && n)) return PC_ERR_ARG;
+    if (encoded_len < 8) return PC_ERR_TRUNCATED;
+    const size_t nw = encoded_len / 4;
+    size_t p = 2;
+    auto word = [&](size_t i) { uint32_t w; std::memcpy(&w, encoded + 4 * i, 4); return w; };
+    uint64_t x = (uint64_t)word(0) | ((uint64_t)word(1) << 32);                       // Rans64DecInit, rans64.h:107-115
+    bool trunc = false;
+    auto renorm = [&]() { if (x < kRansL) { if (p >= nw) { trunc = true; return; } x = (x << 32) | word(p++); } };
+    auto get_bits = [&]() -> int32_t {                                                 // Rans64DecGetBits, rans_interface.cpp:80-96
+        const int32_t v = (int32_t)(x & ((1u << kBypassBits) - 1));
+        x >>= kBypassBits;
+        renorm();
+        return v;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const int32_t ci = indexes[i];
+        if (ci < 0 || ci >= n_cdf) return PC_ERR_INDEX;
+        const int32_t len = cdf_sizes[ci];
+        if (len < 2 || len > cdf_stride) return PC_ERR_CDF;
+        const int32_t* cdf = cdfs + (size_t)ci * cdf_stride;
+        const int32_t max_value = len - 2;
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);                                   // Rans64DecGet
+        // last s in [0, len-2] with cdf[s] <= cf  (== find_if(first > cf) - 1, rans_interface.cpp:238-241)
+        int32_t lo = 0, hi = len - 1;
+        while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((uint32_t)cdf[mid] <= cf) lo = mid; else hi = mid; }
+        const int32_t s = lo;
+        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+        x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFFu) - start;               // Rans64DecAdvance, rans64.h:126-142
+        renorm();
+        int32_t value = s;
+        if (value == max_value) {                                                      // :247-269
+            int32_t val = get_bits();
+            int32_t n_bypass = val;
+            while (val == kBypassMax) { val = get_bits(); n_bypass += val; if (trunc) return PC_ERR_TRUNCATED; }
+            int32_t raw = 0;
+            for (int32_t j = 0; j < n_bypass; ++j) { val = get_bits(); if (j < 8) raw |= val << (j * kBypassBits); }
+            value = raw >> 1;
+            if (raw & 1) value = -value - 1; else value += max_value;
+        }
+        if (trunc) return PC_ERR_TRUNCATED;
+        out[i] = value + offsets[ci];
+    }
+    return PC_OK;
+}
+
+extern "C" int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf)
+{
+    if (!pmf || !cdf || n <= 0 || precision < 1 || precision > 16) return PC_ERR_ARG;
+    cdf[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        const float p = pmf[i];
+        if (!(p >= 0.0f) || !std::isfinite(p)) return PC_ERR_CDF;
+        cdf[i + 1] = (uint32_t)std::round(p * (float)(1 << precision));               // ops.cpp:20-21
+    }
+    uint32_t total = 0;
+    for (int i = 0; i <= n; ++i) total += cdf[i];                                     // :23 (uint32 accumulate)
+    if (total == 0) return PC_ERR_CDF;
+    for (int i = 0; i <= n; ++i) cdf[i] = (uint32_t)((((uint64_t)1 << precision) * cdf[i]) / total);   // :25-28
+    for (int i = 1; i <= n; ++i) cdf[i] += cdf[i - 1];                                // :30
+    cdf[n] = 1u << precision;                                                         // :31
+    for (int i = 0; i < n; ++i) {                                                     // :33-58
+        if (cdf[i] != cdf[i + 1]) continue;
+        uint32_t best_freq = ~0u;
+        int best = -1;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t f = cdf[j + 1] - cdf[j];
+            if (f > 1 && f < best_freq) { best_freq = f; best = j; }
+        }
+        if (best < 0) return PC_ERR_CDF;
+        if (best < i) { for (int j = best + 1; j <= i; ++j) cdf[j]--; }
+        else { for (int j = i + 1; j <= best; ++j) cdf[j]++; }
+    }
+    return PC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// thread pool: parallel_for over independent streams
+// ------------------------------------------------------------------------------------------
+namespace pc {
+
+struct ThreadPool::Impl {
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    const std::function<void(size_t)>* fn = nullptr;
+    size_t n_items = 0;
+    std::atomic<size_t> next{0};
+    size_t active = 0;
+    uint64_t generation = 0;
+    bool stop = false;
+};
+
+ThreadPool::ThreadPool(int n_threads) : impl_(new Impl)
+{
+    if (n_threads <= 0) {
+        unsigned hc = std::thread::hardware_concurrency();
+        n_threads = hc ? (int)hc : 4;
+        if (n_threads > 32) n_threads = 32;
+    }
+    n_ = n_threads;
+    for (int t = 0; t < n_threads - 1; ++t) {
+        impl_->workers.emplace_back([this] {
+            Impl& s = *impl_;
+            uint64_t seen = 0;
+            for (;;) {
+                std::unique_lock<std::mutex> lk(s.mu);
+                s.cv_work.wait(lk, [&] { return s.stop || s.generation != seen; });
+                if (s.stop) return;
+                seen = s.generation;
+                const auto* fn = s.fn;
+                const size_t n = s.n_items;
+                lk.unlock();
+                for (;;) { const size_t i = s.next.fetch_add(1); if (i >= n) break; (*fn)(i); }
+                lk.lock();
+                if (--s.active == 0) s.cv_done.notify_all();
+            }
+        });
+    }
+}
+
+ThreadPool::~ThreadPool()
+{
+    { std::lock_guard<std::mutex> lk(impl_->mu); impl_->stop = true; }
+    impl_->cv_work.notify_all();
+    for (auto& w : impl_->workers) w.join();
+    delete impl_;
+}
+
+void ThreadPool::parallel_for(size_t n, const std::function<void(size_t)>& fn)
+{
+    Impl& s = *impl_;
+    if (n == 0) return;
+    if (s.workers.empty() || n == 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    {
+        std::lock_guard<std::mutex> lk(s.mu);
+        s.fn = &fn; s.n_items = n; s.next = 0; s.active = s.workers.size(); ++s.generation;
+    }
+    s.cv_work.notify_all();
+    for (;;) { const size_t i = s.next.fetch_add(1); if (i >= n) break; fn(i); }
+    std::unique_lock<std::mutex> lk(s.mu);
+    s.cv_done.wait(lk, [&] { return s.active == 0; });
+}
+
+ThreadPool& default_pool()
+{
+    static ThreadPool pool(0);
+    return pool;
+}
+
+}  // namespace pc
+
+extern "C" int pc_rans_encode_batch(const int32_t* symbols, const int32_t* indexes, size_t n_streams, size_t n,
+                                    const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                    const int32_t* cdf_sizes, const int32_t* offsets,
+                                    uint8_t* out, size_t out_stride, size_t* out_lens, int n_threads)
+{
+    if (!out || !out_lens || (out_stride & 3)) return PC_ERR_ARG;
+    std::atomic<int> rc{PC_OK};
+    auto job = [&](size_t s) {
+        const int r = pc_rans_encode_with_indexes(symbols + s * n, indexes + s * n, n, cdfs, n_cdf, cdf_stride, cdf_sizes,
+                                                  offsets, out + s * out_stride, out_stride, &out_lens[s]);
+        if (r != PC_OK) rc = r;
+    };
+    if (n_threads == 1) for (size_t s = 0; s < n_streams; ++s) job(s);
+    else pc::default_pool().parallel_for(n_streams, job);
+    return rc;
+}
+
+extern "C" int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams,
+                                    const int32_t* indexes, size_t n,
+                                    const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                    const int32_t* cdf_sizes, const int32_t* offsets,
+                                    int32_t* out, int n_threads)
+{
+    if (!encoded || !encoded_lens) return PC_ERR_ARG;
+    std::atomic<int> rc{PC_OK};
+    auto job = [&](size_t s) {
+        const int r = pc_rans_decode_with_indexes(encoded[s], encoded_lens[s], indexes + s * n, n, cdfs, n_cdf, cdf_stride,
+                                                  cdf_sizes, offsets, out + s * n);
+        if (r != PC_OK) rc = r;
+    };
+    if (n_threads == 1) for (size_t s = 0; s < n_streams; ++s) job(s);
+    else pc::default_pool().parallel_for(n_streams, job);
+    return rc;
+}
+
+extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.1 (gfx950)"; }
+
+extern "C" const char* pc_strerror(int code)
+{
+    switch (code) {
+    case PC_OK: return "ok";
+    case PC_ERR_ARG: return "invalid argument or unsupported shape";
+    case PC_ERR_INDEX: return "CDF index out of range";
+    case PC_ERR_BUFFER: return "output buffer too small";
+    case PC_ERR_TRUNCATED: return "truncated bitstream";
+    case PC_ERR_CDF: return "malformed CDF / pmf";
+    case PC_ERR_HIP: return "HIP runtime error";
+    case PC_ERR_NOMEM: return "out of memory";
+    case PC_ERR_STATE: return "object not ready (tables or weights missing; run update()/finalize first)";
+    case PC_ERR_MISSING: return "state_dict tensor missing or of the wrong shape";
+    default: return "unknown error";
+    }
+}

@@ -1,0 +1,359 @@
+// pc_stages.hip -- the non-GEMM device stages of the codec:
+//   * shifted-window attention core                         (layers/win_attention.py:84-115,153-207)
+//   * per-image variance-quantile mask threshold            (layers/masking.py:205-223, torch.quantile)
+//   * GaussianConditional index + quantise + dequantise     (entropy_models.py:126-165,661-666; CHProg_cnn.py:751-755,819-834)
+//   * EntropyBottleneck quantise / dequantise               (entropy_models.py:508-522)
+// All are HBM/L2-bound byte or element passes: coalesced 128-B rows in, LDS-transposed
+// coalesced rows out (the rANS coder consumes symbols in C,H,W raster order while the
+// network runs NHWC), wavefront-wide (64-lane) reductions, no atomics on floats.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pc_math.h"
+#include "pc_device.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// window attention: one 64-lane wave handles 64/T (window, head) pairs, lane = query token.
+// s_j = fmaf-chain_e (q[e]*scale) * k_j[e];  += bias;  += shift mask;  softmax;  o[e] = fmaf-chain_j p_j v_j[e]
+// (same chains as oracle/pc_oracle.c:orc_win_attention)
+// ------------------------------------------------------------------------------------------
+template <int WS, int D>
+__global__ __launch_bounds__(256) void win_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
+                                                            int B, int H, int W, int C, int heads, int shift, float scale,
+                                                            float* __restrict__ out, int npairs)
+{
+    constexpr int T = WS * WS, G = 64 / T;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / T, i = lane % T;
+    const int pair = (blockIdx.x * 4 + wave) * G + sub;
+    if (pair >= npairs) return;
+    const int win = pair / heads, h = pair % heads;
+    const int nwx = W / WS, nwy = H / WS;
+    const int b = win / (nwx * nwy), wy = (win / nwx) % nwy, wx = win % nwx;
+    const int C3 = 3 * C;
+
+    auto token = [&](int t, int& reg) -> int64_t {
+        const int ys = wy * WS + t / WS, xs = wx * WS + t % WS;
+        const int y = (ys + shift) % H, x = (xs + shift) % W;
+        const int ry = ys < H - WS ? 0 : (ys < H - shift ? 1 : 2);
+        const int rx = xs < W - WS ? 0 : (xs < W - shift ? 1 : 2);
+        reg = ry * 3 + rx;
+        return ((int64_t)b * H + y) * W + x;
+    };
+
+    int reg_i;
+    const int64_t pix_i = token(i, reg_i);
+    float q[D];
+    {
+        const float4* qp = reinterpret_cast<const float4*>(qkv + pix_i * C3 + h * D);
+#pragma unroll
+        for (int e = 0; e < D / 4; ++e) {
+            const float4 v = qp[e];
+            q[4 * e + 0] = v.x * scale; q[4 * e + 1] = v.y * scale; q[4 * e + 2] = v.z * scale; q[4 * e + 3] = v.w * scale;
+        }
+    }
+    float s[T];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        int reg_j;
+        const int64_t pix_j = token(j, reg_j);
+        const float4* kp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + C + h * D);
+        float acc = 0.0f;
+#pragma unroll
+        for (int e = 0; e < D / 4; ++e) {
+            const float4 k = kp[e];
+            acc = fmaf(q[4 * e + 0], k.x, acc);
+            acc = fmaf(q[4 * e + 1], k.y, acc);
+            acc = fmaf(q[4 * e + 2], k.z, acc);
+            acc = fmaf(q[4 * e + 3], k.w, acc);
+        }
+        acc = acc + bias[((int64_t)h * T + i) * T + j];
+        if (shift > 0) acc = acc + (reg_i != reg_j ? -100.0f : 0.0f);
+        s[j] = acc;
+        m = acc > m ? acc : m;
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < T; ++j) { s[j] = pc_expf(s[j] - m); sum = sum + s[j]; }
+#pragma unroll
+    for (int j = 0; j < T; ++j) s[j] = s[j] / sum;
+    float o[D];
+#pragma unroll
+    for (int e = 0; e < D; ++e) o[e] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < T; ++j) {
+        int reg_j;
+        const int64_t pix_j = token(j, reg_j);
+        const float4* vp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + 2 * C + h * D);
+#pragma unroll
+        for (int e = 0; e < D / 4; ++e) {
+            const float4 v = vp[e];
+            o[4 * e + 0] = fmaf(s[j], v.x, o[4 * e + 0]);
+            o[4 * e + 1] = fmaf(s[j], v.y, o[4 * e + 1]);
+            o[4 * e + 2] = fmaf(s[j], v.z, o[4 * e + 2]);
+            o[4 * e + 3] = fmaf(s[j], v.w, o[4 * e + 3]);
+        }
+    }
+    float4* op = reinterpret_cast<float4*>(out + pix_i * C + h * D);
+#pragma unroll
+    for (int e = 0; e < D / 4; ++e) op[e] = make_float4(o[4 * e], o[4 * e + 1], o[4 * e + 2], o[4 * e + 3]);
+}
+
+// ------------------------------------------------------------------------------------------
+// quantile threshold: exact order statistics by MSB-first radix select (4 x 8-bit digits),
+// one 1024-thread workgroup per image, integer LDS histograms only (deterministic).
+// thr = ATen lerp(s[lo], s[hi], w) with rank = q*(n-1) evaluated in float32 (see oracle orc_quantile).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t fkey(float f)
+{
+    const uint32_t u = pc_f2bits(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);   // total order: -inf < ... < -0 < +0 < ... < +inf < NaN(+)
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k)
+{
+    return pc_bits2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+__global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
+                                                           float* __restrict__ thr)
+{
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sh_prefix, sh_rank, sh_less, sh_eq, sh_nan, sh_min;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t n = (int64_t)HW * C;
+    const float* base = scale + (int64_t)b * HW * ld;
+    auto elem = [&](int64_t e) -> float { const int64_t p = e / C; return base[p * ld + (e - p * C)]; };
+
+    const float rank = q * (float)(n - 1);
+    const float lo_f = floorf(rank), hi_f = ceilf(rank);
+    const uint32_t lo = (uint32_t)lo_f, hi = (uint32_t)hi_f;
+    const float w = rank - lo_f;
+
+    if (tid == 0) { sh_prefix = 0; sh_rank = lo; sh_less = 0; sh_nan = 0; sh_min = 0xffffffffu; }
+    uint32_t prefix_mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int k = tid; k < 256; k += 1024) hist[k] = 0;
+        __syncthreads();
+        const uint32_t prefix = sh_prefix;
+        uint32_t nan_local = 0;
+        for (int64_t e = tid; e < n; e += 1024) {
+            const float f = elem(e);
+            if (pass == 0 && f != f) nan_local++;
+            const uint32_t k = fkey(f);
+            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        if (pass == 0 && nan_local) atomicAdd(&sh_nan, nan_local);
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t r = sh_rank, less = sh_less, d = 0;
+            for (; d < 256; ++d) { if (r < hist[d]) break; r -= hist[d]; less += hist[d]; }
+            sh_prefix = prefix | (d << shift);
+            sh_rank = r; sh_less = less; sh_eq = hist[d < 256 ? d : 255];
+        }
+        __syncthreads();
+        prefix_mask |= 0xffu << shift;
+    }
+    const uint32_t key_lo = sh_prefix;
+    uint32_t key_hi = key_lo;
+    if (hi != lo && hi >= sh_less + sh_eq) {
+        // next order statistic: the smallest key above key_lo
+        uint32_t mn = 0xffffffffu;
+        for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = fkey(elem(e)); if (k > key_lo && k < mn) mn = k; }
+        for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
+        if ((tid & 63) == 0) atomicMin(&sh_min, mn);
+        __syncthreads();
+        key_hi = sh_min;
+    }
+    if (tid == 0) {
+        float r;
+        if (sh_nan) r = pc_bits2f(0x7fc00000u);
+        else {
+            const float a = fkey_inv(key_lo), bb = fkey_inv(key_hi);
+            const float d = bb - a;
+            r = (fabsf(w) < 0.5f) ? fmaf(w, d, a) : fmaf(-d, 1.0f - w, bb);
+        }
+        thr[b] = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// GaussianConditional stages.  Tile = 64 pixels x 32 channels; NHWC in, [B][C][HW] out via LDS transpose.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int gc_index(float s, const float* table, int nt, float bound)
+{
+    // entropy_models.py:661-666: idx = (nt-1) - #{k < nt-1 : max(s, bound) <= table[k]}  ==  #{k < nt-1 : table[k] < max(s, bound)}
+    if (s != s) return nt - 1;                 // torch.max propagates NaN; every compare is then false
+    s = s > bound ? s : bound;
+    int lo = 0, hi = nt - 1;                   // first k in [0, nt-1) with table[k] >= s
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (table[mid] < s) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+template <int MODE>   // 0 = encoder (index+quantise+dequantise), 1 = decoder index only
+__global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
+{
+    constexpr int TP = 64, CC = 32;
+    __shared__ int32_t t_sym[CC][TP + 1];
+    __shared__ int32_t t_idx[CC][TP + 1];
+    __shared__ float t_msk[CC][TP + 1];
+    __shared__ float s_table[64];
+    const int b = blockIdx.y, p0 = blockIdx.x * TP, tid = threadIdx.x;
+    if (tid < p.ntable && tid < 64) s_table[tid] = p.table[tid];
+    __syncthreads();
+    float thr = 0.0f;
+    if (p.mask_mode == 1) thr = p.thr[b];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        const int px = e >> 5, c = e & 31;
+        if (p0 + px >= p.HW) continue;
+        const int64_t pix = (int64_t)b * p.HW + p0 + px;
+        const float s = p.scale[pix * p.ld_scale + c];
+        float m = 1.0f;
+        if (p.mask_mode == 1) m = (s >= thr) ? 1.0f : 0.0f;
+        else if (p.mask_mode == 3) m = 0.0f;
+        const float sm = (p.mask_mode == 0) ? s : s * m;
+        t_idx[c][px] = gc_index(sm, s_table, p.ntable, p.bound);
+        t_msk[c][px] = m;
+        if (MODE == 0) {
+            const float mu = p.mu[pix * p.ld_mu + c];
+            float y = p.y[pix * p.ld_y + c];
+            if (p.ybase) y = y - p.ybase[pix * p.ld_ybase + c];          // delta_encode, CHProg_cnn.py:780-781
+            float v = y - mu;                                              // entropy_models.py:137-139 / CHProg_cnn.py:830
+            if (p.mask_mode != 0) v = v * m;
+            const int32_t sym = (int32_t)pc_roundevenf(v);
+            t_sym[c][px] = sym;
+            p.yhat[pix * p.ld_yhat + c] = (float)sym + mu;                 // CHProg_cnn.py:754-755,833-834
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        const int c = e >> 6, px = e & 63;
+        if (p0 + px >= p.HW) continue;
+        const int64_t o = ((int64_t)b * CC + c) * p.HW + p0 + px;
+        p.idx[o] = t_idx[c][px];
+        if (MODE == 0) p.sym[o] = t_sym[c][px];
+        if (p.mask) p.mask[o] = t_msk[c][px];
+    }
+}
+
+// decoder: yhat(NHWC) = float(sym[B][C][HW]) + mu(NHWC)          entropy_models.py:159-165, CHProg_cnn.py:896,971
+__global__ __launch_bounds__(256) void gc_dequant_kernel(const pc_prep_params p)
+{
+    constexpr int TP = 64, CC = 32;
+    __shared__ int32_t t_sym[CC][TP + 1];
+    const int b = blockIdx.y, p0 = blockIdx.x * TP, tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        const int c = e >> 6, px = e & 63;
+        if (p0 + px < p.HW) t_sym[c][px] = p.sym[((int64_t)b * CC + c) * p.HW + p0 + px];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int e = tid + 256 * k;
+        const int px = e >> 5, c = e & 31;
+        if (p0 + px >= p.HW) continue;
+        const int64_t pix = (int64_t)b * p.HW + p0 + px;
+        p.yhat[pix * p.ld_yhat + c] = (float)t_sym[c][px] + p.mu[pix * p.ld_mu + c];
+    }
+}
+
+// EntropyBottleneck: z NHWC [B][HW][C] -> sym [B][C][HW] (= round(z - median_c)), zhat NHWC = float(sym) + median_c
+__global__ void eb_quant_kernel(const float* __restrict__ z, int B, int HW, int C, const float* __restrict__ med,
+                                int32_t* __restrict__ sym, float* __restrict__ zhat)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int b = (int)(pix / HW), px = (int)(pix % HW);
+        const float m = med[c];
+        const int32_t s = (int32_t)pc_roundevenf(z[e] - m);
+        sym[((int64_t)b * C + c) * HW + px] = s;
+        zhat[e] = (float)s + m;
+    }
+}
+
+__global__ void eb_dequant_kernel(const int32_t* __restrict__ sym, int B, int HW, int C, const float* __restrict__ med,
+                                  float* __restrict__ zhat)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int b = (int)(pix / HW), px = (int)(pix % HW);
+        zhat[e] = (float)sym[((int64_t)b * C + c) * HW + px] + med[c];
+    }
+}
+
+}  // namespace
+
+#define PC_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP)
+
+int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int ws,
+                            int shift, float scale, float* out, hipStream_t stream)
+{
+    if (heads <= 0 || C % heads || H % ws || W % ws || shift < 0 || shift >= ws) return PC_ERR_ARG;
+    const int d = C / heads, T = ws * ws;
+    const int npairs = B * (H / ws) * (W / ws) * heads;
+    const int per_block = 4 * (64 / T);
+    dim3 grid((npairs + per_block - 1) / per_block), block(256);
+    if (ws == 8 && d == 24)
+        hipLaunchKernelGGL((win_attention_kernel<8, 24>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+    else if (ws == 4 && d == 80)
+        hipLaunchKernelGGL((win_attention_kernel<4, 80>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+    else if (ws == 4 && d == 40)
+        hipLaunchKernelGGL((win_attention_kernel<4, 40>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+    else
+        return PC_ERR_ARG;
+    return PC_LAUNCH_CHECK();
+}
+
+int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t*, hipStream_t stream)
+{
+    if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
+    hipLaunchKernelGGL(quantile_thr_kernel, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
+    return PC_LAUNCH_CHECK();
+}
+size_t pc_quantile_work_bytes(int) { return 0; }
+
+int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream)
+{
+    if (p.C != 32 || p.ntable > 64 || p.ntable < 2) return PC_ERR_ARG;
+    hipLaunchKernelGGL((gc_prep_kernel<0>), dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    return PC_LAUNCH_CHECK();
+}
+int pc_prep_dec_index_launch(const pc_prep_params& p, hipStream_t stream)
+{
+    if (p.C != 32 || p.ntable > 64 || p.ntable < 2) return PC_ERR_ARG;
+    hipLaunchKernelGGL((gc_prep_kernel<1>), dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    return PC_LAUNCH_CHECK();
+}
+int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream)
+{
+    if (p.C != 32) return PC_ERR_ARG;
+    hipLaunchKernelGGL(gc_dequant_kernel, dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    return PC_LAUNCH_CHECK();
+}
+int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* med, int32_t* sym, float* zhat, hipStream_t stream)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(eb_quant_kernel, dim3(blocks), dim3(256), 0, stream, z, B, HW, C, med, sym, zhat);
+    return PC_LAUNCH_CHECK();
+}
+int pc_eb_dequant_launch(const int32_t* sym, int B, int HW, int C, const float* med, float* zhat, hipStream_t stream)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(eb_dequant_kernel, dim3(blocks), dim3(256), 0, stream, sym, B, HW, C, med, zhat);
+    return PC_LAUNCH_CHECK();
+}

@@ -1,0 +1,151 @@
+"""Entropy-model tables (init-time host logic) and the drop-in entropy-coder classes.
+
+* ``gaussian_conditional_tables`` / ``entropy_bottleneck_tables`` mirror
+  ``GaussianConditional.update`` (reference src/compress/entropy_models/entropy_models.py:599-624)
+  and ``EntropyBottleneck.update`` (:354-393): float PMFs are evaluated with the same ATen
+  CPU ops the reference uses and quantised by ``pc_pmf_to_quantized_cdf`` (the native
+  replacement of ``compressai._CXX.pmf_to_quantized_cdf``, cpp_exts/ops/ops.cpp:10-67).
+* ``RansEncoder`` / ``RansDecoder`` / ``pmf_to_quantized_cdf`` reproduce the Python surface of
+  ``compressai.ans`` and ``compressai._CXX`` (cpp_exts/rans/rans_interface.cpp:352-372,
+  ops.cpp:69-76) on top of the C ABI, so ``entropy_models.py:13,33-36`` can import them unchanged.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import check, lib
+
+
+@dataclass
+class CdfTables:
+    cdf: np.ndarray      # [n, stride] int32   (_quantized_cdf)
+    length: np.ndarray   # [n] int32           (_cdf_length)
+    offset: np.ndarray   # [n] int32           (_offset)
+
+    def __post_init__(self):
+        self.cdf = np.ascontiguousarray(self.cdf, np.int32)
+        self.length = np.ascontiguousarray(self.length, np.int32).reshape(-1)
+        self.offset = np.ascontiguousarray(self.offset, np.int32).reshape(-1)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def pmf_to_quantized_cdf(pmf, precision=16):
+    """compressai._CXX.pmf_to_quantized_cdf(pmf: list[float], precision) -> list[int]  (ops.cpp:10)."""
+    p = np.ascontiguousarray(pmf, np.float32).reshape(-1)
+    out = np.zeros(p.size + 1, np.uint32)
+    check(lib().pc_pmf_to_quantized_cdf(_ptr(p), p.size, int(precision), _ptr(out)), "pmf_to_quantized_cdf")
+    return out.tolist()
+
+
+def _tables_from_lists(cdfs, sizes, offsets):
+    n = len(cdfs)
+    stride = max(len(r) for r in cdfs)
+    dense = np.zeros((n, stride), np.int32)
+    for i, r in enumerate(cdfs):
+        dense[i, : len(r)] = r
+    return CdfTables(dense, np.asarray(sizes, np.int32), np.asarray(offsets, np.int32))
+
+
+class RansEncoder:
+    """compressai.ans.RansEncoder (rans_interface.cpp:193-204)."""
+
+    def encode_with_indexes(self, symbols, indexes, cdfs, cdfs_sizes, offsets) -> bytes:
+        t = cdfs if isinstance(cdfs, CdfTables) else _tables_from_lists(cdfs, cdfs_sizes, offsets)
+        return rans_encode(symbols, indexes, t)
+
+
+class RansDecoder:
+    """compressai.ans.RansDecoder.decode_with_indexes (rans_interface.cpp:206-275)."""
+
+    def decode_with_indexes(self, encoded, indexes, cdfs, cdfs_sizes, offsets):
+        t = cdfs if isinstance(cdfs, CdfTables) else _tables_from_lists(cdfs, cdfs_sizes, offsets)
+        return rans_decode(encoded, indexes, t).tolist()
+
+
+def rans_encode(symbols, indexes, t: CdfTables) -> bytes:
+    s = np.ascontiguousarray(symbols, np.int32).reshape(-1)
+    i = np.ascontiguousarray(indexes, np.int32).reshape(-1)
+    if s.size != i.size:
+        raise ValueError("`symbols` and `indexes` should have the same size.")
+    cap = lib().pc_rans_bound(s.size)
+    out = np.empty(cap // 4, np.uint32)
+    n = C.c_size_t(0)
+    check(lib().pc_rans_encode_with_indexes(_ptr(s), _ptr(i), s.size, _ptr(t.cdf), t.cdf.shape[0], t.cdf.shape[1],
+                                            _ptr(t.length), _ptr(t.offset), _ptr(out), cap, C.byref(n)), "rans_encode")
+    return out.view(np.uint8)[: n.value].tobytes()
+
+
+def rans_decode(encoded: bytes, indexes, t: CdfTables) -> np.ndarray:
+    i = np.ascontiguousarray(indexes, np.int32).reshape(-1)
+    buf = np.frombuffer(encoded, np.uint8)
+    out = np.empty(i.size, np.int32)
+    check(lib().pc_rans_decode_with_indexes(_ptr(buf), buf.size, _ptr(i), i.size, _ptr(t.cdf), t.cdf.shape[0],
+                                            t.cdf.shape[1], _ptr(t.length), _ptr(t.offset), _ptr(out)), "rans_decode")
+    return out
+
+
+def _pmf_to_cdf(pmf, tail_mass, pmf_length, max_length):
+    """EntropyModel._pmf_to_cdf (entropy_models.py:172-180)."""
+    cdf = np.zeros((len(pmf_length), max_length + 2), np.int32)
+    for i in range(len(pmf_length)):
+        prob = np.concatenate([pmf[i, : pmf_length[i]], tail_mass[i]])
+        c = pmf_to_quantized_cdf(prob, 16)
+        cdf[i, : len(c)] = c
+    return cdf
+
+
+def gaussian_conditional_tables(scale_table, tail_mass=1e-9) -> CdfTables:
+    """GaussianConditional.update (entropy_models.py:599-624)."""
+    import scipy.stats
+    import torch
+    st = torch.as_tensor(np.asarray(scale_table, np.float32))
+    multiplier = -scipy.stats.norm.ppf(tail_mass / 2)
+    pmf_center = torch.ceil(st * multiplier).int()
+    pmf_length = 2 * pmf_center + 1
+    max_length = int(pmf_length.max())
+    samples = torch.abs(torch.arange(max_length).int() - pmf_center[:, None]).float()
+    s = st.unsqueeze(1).float()
+
+    def cum(v):                                   # _standardized_cumulative :578-582
+        return 0.5 * torch.erfc(float(-(2 ** -0.5)) * v)
+
+    upper = cum((0.5 - samples) / s)
+    lower = cum((-0.5 - samples) / s)
+    pmf = upper - lower
+    tail = 2 * lower[:, :1]
+    cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+    return CdfTables(cdf, (pmf_length + 2).numpy(), (-pmf_center).numpy())
+
+
+def entropy_bottleneck_tables(sd, prefix="entropy_bottleneck") -> CdfTables:
+    """EntropyBottleneck.update (entropy_models.py:354-393, _logits_cumulative :400-419)."""
+    import torch
+    import torch.nn.functional as F
+    g = lambda k: torch.as_tensor(np.asarray(sd[f"{prefix}.{k}"])).float().cpu()
+    q = g("quantiles")
+    medians = q[:, 0, 1]
+    minima = torch.clamp(torch.ceil(medians - q[:, 0, 0]).int(), min=0)
+    maxima = torch.clamp(torch.ceil(q[:, 0, 2] - medians).int(), min=0)
+    pmf_start = medians - minima
+    pmf_length = maxima + minima + 1
+    max_length = int(pmf_length.max())
+    samples = torch.arange(max_length)[None, :] + pmf_start[:, None, None]
+
+    def logits(x):
+        for i in range(5):
+            x = torch.matmul(F.softplus(g(f"_matrix{i}")), x)
+            x = x + g(f"_bias{i}")
+            if i < 4:
+                x = x + torch.tanh(g(f"_factor{i}")) * torch.tanh(x)
+        return x
+
+    lower, upper = logits(samples - 0.5), logits(samples + 0.5)
+    sign = -torch.sign(lower + upper)
+    pmf = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))[:, 0, :]
+    tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
+    cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
+    return CdfTables(cdf, (pmf_length + 2).numpy(), (-minima).numpy())

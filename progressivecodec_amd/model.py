@@ -1,0 +1,197 @@
+"""Host-side mirror of the reference's model class for the compress()/decompress() path.
+
+``ChannelProgresssiveWACNN`` here has the same constructor keywords, method names, argument
+meaning, return structure and error behaviour as the reference class
+(/root/reference/src/compress/models/CHProg_cnn.py:30, :686, :849; base class models/cnn.py:23,
+:137, :195), but owns no torch modules: weights live in HBM inside the native codec object
+(libpcodec.so, include/pcodec.h) and both entry points are native HIP launch sequences.
+PyTorch is used only to hold the input / output device tensors and to supply the HIP stream.
+"""
+import ctypes as C
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+from . import entropy
+from ._lib import check, lib
+from .arch import CodecConfig, param_spec
+
+_MASK_POL = {"point-based-std": 0, "two-levels": 1}
+_DT = {"float32": 0, "int32": 1, "int64": 2}
+
+
+def get_scale_table(min=0.11, max=256, levels=64):
+    """models/cnn.py:14-20."""
+    import torch
+    return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
+
+
+class ChannelProgresssiveWACNN:
+    def __init__(self, N=192, M=640, division_dimension=(320, 640), dim_chunk=32, multiple_decoder=True,
+                 multiple_encoder=False, multiple_hyperprior=True, mask_policy="two-levels", lmbda_list=(0.0055, 0.04),
+                 joiner_policy="res", support_progressive_slices=5, delta_encode=True, device="cuda:0", **kwargs):
+        self.cfg = CodecConfig(N=N, M=M, division_dimension=tuple(division_dimension), dim_chunk=dim_chunk,
+                               multiple_decoder=multiple_decoder, multiple_encoder=multiple_encoder,
+                               multiple_hyperprior=multiple_hyperprior, delta_encode=delta_encode,
+                               joiner_policy=joiner_policy, support_progressive_slices=support_progressive_slices,
+                               mask_policy=mask_policy)
+        self.cfg.check_supported()
+        self.mask_policy = mask_policy
+        self.lmbda_list = list(lmbda_list)
+        import torch
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("progressivecodec_amd runs on a HIP device only (no CPU fallback)")
+        self._h = C.c_void_p()
+        check(lib().pc_codec_create(C.byref(self._h), self.device.index or 0), "pc_codec_create")
+        self._sd = None
+        self._gc = None
+        self._eb = None
+        self._finalized = False
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            lib().pc_codec_destroy(h)
+            self._h = C.c_void_p()
+
+    # ------------------------------------------------------------------ nn.Module-like surface
+    def eval(self):
+        return self
+
+    def to(self, device):
+        return self
+
+    def load_state_dict(self, state_dict, strict=True):
+        """models/cnn.py:195-202 / base.py:62-70: accepts the reference's 1019-key state_dict."""
+        spec = param_spec(self.cfg)
+        missing = [k for k in spec if k not in state_dict]
+        unexpected = [k for k in state_dict if k not in spec]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:5]}... unexpected {unexpected[:5]}...")
+        sd = OrderedDict()
+        for k, (shape, dtype, kind) in spec.items():
+            if k not in state_dict:
+                continue
+            v = state_dict[k]
+            a = v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+            a = np.ascontiguousarray(a.astype(dtype, copy=False))
+            if kind != "table" and tuple(a.shape) != tuple(shape):
+                raise RuntimeError(f"size mismatch for {k}: {tuple(a.shape)} vs {tuple(shape)}")
+            sd[k] = a
+            if kind == "table":
+                continue
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            check(lib().pc_codec_set_tensor(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), _DT[dtype], shp, a.ndim),
+                  f"set_tensor({k})")
+        self._sd = sd
+        check(lib().pc_codec_finalize(self._h), "pc_codec_finalize")
+        self._finalized = True
+        for which, p in ((0, "gaussian_conditional"), (1, "entropy_bottleneck")):
+            cdf = sd.get(p + "._quantized_cdf")
+            if cdf is not None and cdf.size > 0:
+                self._set_tables(which, entropy.CdfTables(cdf, sd[p + "._cdf_length"], sd[p + "._offset"]))
+        return self
+
+    def _set_tables(self, which, t):
+        check(lib().pc_codec_set_tables(self._h, which, t.cdf.ctypes.data_as(C.c_void_p), t.cdf.shape[0], t.cdf.shape[1],
+                                        t.length.ctypes.data_as(C.c_void_p), t.offset.ctypes.data_as(C.c_void_p)),
+              "pc_codec_set_tables")
+        if which == 0:
+            self._gc = t
+        else:
+            self._eb = t
+
+    def update(self, scale_table=None, force=False):
+        """models/cnn.py:137-142 -> GaussianConditional.update_scale_table / CompressionModel.update."""
+        if self._sd is None:
+            raise ValueError("load_state_dict() first")
+        updated = False
+        if self._gc is None or force:
+            if scale_table is not None:
+                raise NotImplementedError("a custom scale_table must be part of the state_dict (module buffer)")
+            self._set_tables(0, entropy.gaussian_conditional_tables(self._sd["gaussian_conditional.scale_table"]))
+            updated = True
+        if self._eb is None or force:
+            self._set_tables(1, entropy.entropy_bottleneck_tables(self._sd))
+            updated = True
+        return updated
+
+    # ------------------------------------------------------------------ the hot path
+    def _stream(self):
+        import torch
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def compress(self, x, quality=0.0, mask_pol=None, cust_map=None):
+        """CHProg_cnn.py:686-847.  Returns {"strings": [y_strings, z_strings], "shape", "masks"}."""
+        import torch
+        if cust_map is not None:
+            raise NotImplementedError("cust_map masks are out of scope (SURVEY.md section 8f)")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in _MASK_POL:
+            raise NotImplementedError(f"mask policy {mask_pol!r}")
+        if self._gc is None or self._eb is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")           # entropy_models.py:182-184
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("Invalid `inputs` size. Expected a [B,3,H,W] tensor.")
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (pad as training/step.py:318 does)")
+        x = x.to(self.device, torch.float32).contiguous()
+        h, w = H // 16, W // 16
+        n_enh = 0 if quality <= 0 else 10
+        masks = torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if n_enh else None
+        check(lib().pc_codec_compress(self._h, C.c_void_p(x.data_ptr()), B, H, W, float(quality), _MASK_POL[mask_pol],
+                                      C.c_void_p(masks.data_ptr()) if masks is not None else None, self._stream()),
+              "pc_codec_compress")
+        ns = lib().pc_codec_num_slices(self._h)
+        p, n = C.c_void_p(), C.c_size_t()
+
+        def get(s, b):
+            check(lib().pc_codec_get_string(self._h, s, b, C.byref(p), C.byref(n)), "pc_codec_get_string")
+            return C.string_at(p, n.value)
+
+        y_strings = [[get(s, b) for b in range(B)] for s in range(ns)]
+        z_strings = [get(-1, b) for b in range(B)]
+        return {"strings": [y_strings, z_strings], "shape": torch.Size([H // 64, W // 64]),
+                "masks": [masks[i] for i in range(10)] if masks is not None else []}
+
+    def decompress(self, strings, shape, quality, mask_pol=None, cust_map=None):
+        """CHProg_cnn.py:849-999.  Returns {"x_hat": Tensor[B,3,H,W] in [0,1]}."""
+        import torch
+        if cust_map is not None:
+            raise NotImplementedError("cust_map masks are out of scope (SURVEY.md section 8f)")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in _MASK_POL:
+            raise NotImplementedError(f"mask policy {mask_pol!r}")
+        if self._gc is None or self._eb is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if not isinstance(strings, (tuple, list)) or len(strings) != 2:
+            raise ValueError("Invalid `strings` parameter type.")                # entropy_models.py:250-251
+        y_strings, z_strings = strings
+        B = len(z_strings)
+        ns = len(y_strings)
+        if any(len(s) != B for s in y_strings):
+            raise ValueError("Invalid strings or indexes parameters")            # entropy_models.py:253-254
+        zh, zw = int(shape[0]), int(shape[1])
+        flat = [s for sl in y_strings for s in sl]
+        keep = flat + list(z_strings)                                            # keep the bytes objects alive
+        yp = (C.c_char_p * len(flat))(*flat)
+        yl = (C.c_size_t * len(flat))(*[len(s) for s in flat])
+        zp = (C.c_char_p * B)(*z_strings)
+        zl = (C.c_size_t * B)(*[len(s) for s in z_strings])
+        x_hat = torch.empty((B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
+        check(lib().pc_codec_decompress(self._h, yp, yl, ns, zp, zl, B, zh, zw, float(quality), _MASK_POL[mask_pol],
+                                        C.c_void_p(x_hat.data_ptr()), self._stream()), "pc_codec_decompress")
+        del keep
+        return {"x_hat": x_hat}
+
+    # ------------------------------------------------------------------ test taps
+    def read_tap(self, name, dtype=np.float32):
+        n = C.c_size_t()
+        f = lib().pc_codec_read_tap
+        check(f(self._h, name.encode(), None, 0, C.byref(n)), "read_tap")
+        out = np.empty(n.value, dtype)
+        check(f(self._h, name.encode(), out.ctypes.data_as(C.c_void_p), n.value, C.byref(n)), "read_tap")
+        return out

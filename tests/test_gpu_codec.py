@@ -1,0 +1,127 @@
+"""End-to-end GPU parity of compress()/decompress() through the C ABI.
+
+* vs the CPU oracle in the numeric-contract order (backend "cdet"): every byte string, every
+  mask, every symbol/index and x_hat must be IDENTICAL (bit-exact) -- same inputs, same weights.
+* vs the committed goldens of the real reference (tests/golden/e2e.json): bpp and PSNR within the
+  stated tolerances; byte strings equal except where float rounding flips a symbol (reported).
+* size-independent properties at the bench size: encode->decode round trip consistency, batch
+  invariance (an image codes identically at B=1 and inside a batch), mask popcounts.
+"""
+import hashlib
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle.codec_ref import bpp_of, compute_padding, psnr_of  # noqa: E402
+from tests.util import e2e_cases, gpu_codec, inputs, oracle_codec  # noqa: E402
+
+PSNR_TOL_DB = 2e-3      # vs the PyTorch reference (float rounding may flip isolated symbols)
+BPP_TOL = 2e-3
+
+
+def sha(b):
+    return hashlib.sha256(b).hexdigest()
+
+
+def run_case(c):
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    pad, unpad = compute_padding(c["H"], c["W"])
+    xp = F.pad(x, pad)
+    net = gpu_codec()
+    out = net.compress(xp.cuda(), c["quality"], "point-based-std")
+    dec = net.decompress(out["strings"], out["shape"], c["quality"], "point-based-std")
+    x_hat = F.pad(dec["x_hat"].cpu(), unpad).clamp_(0, 1)
+    return x, xp, out, x_hat
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3, 4, 6, 8, 9])
+def test_bit_exact_vs_oracle(idx):
+    c = e2e_cases()[idx]
+    x, xp, out, x_hat = run_case(c)
+    orc = oracle_codec("cdet")
+    ref = orc.compress(xp, c["quality"])
+    ys, zs = out["strings"]
+    rys, rzs = ref["strings"]
+    assert tuple(out["shape"]) == tuple(ref["shape"])
+    assert len(ys) == len(rys)
+    assert zs == rzs, "z strings differ"
+    for s, (a, b) in enumerate(zip(ys, rys)):
+        assert a == b, f"y strings of slice {s} differ"
+    for m, rm in zip(out["masks"], ref["masks"]):
+        assert np.array_equal(m.cpu().numpy(), rm.numpy())
+    rdec = orc.decompress(ref["strings"], ref["shape"], c["quality"])
+    r_x_hat = F.pad(rdec["x_hat"], compute_padding(c["H"], c["W"])[1]).clamp_(0, 1)
+    assert np.array_equal(x_hat.numpy().view(np.uint32), r_x_hat.numpy().view(np.uint32)), \
+        f"x_hat max abs diff {(x_hat - r_x_hat).abs().max().item()}"
+
+
+@pytest.mark.parametrize("idx", range(11))
+def test_vs_reference_goldens(idx):
+    c = e2e_cases()[idx]
+    x, xp, out, x_hat = run_case(c)
+    ys, zs = out["strings"]
+    assert list(out["shape"]) == c["shape"]
+    assert [sha(s) for s in zs] == c["z_sha"], "hyper-latent strings must match the reference exactly"
+    n_str = sum(len(sl) for sl in ys)
+    n_ok = sum(sha(s) == h for sl, hl in zip(ys, c["y_sha"]) for s, h in zip(sl, hl))
+    bpp = bpp_of(out["strings"], c["B"], c["H"], c["W"])
+    psnr = psnr_of(x, x_hat)
+    print(f"{c['case']} q={c['quality']}: {n_ok}/{n_str} y strings identical to the reference; "
+          f"bpp {bpp:.5f} (ref {c['bpp']:.5f}); psnr {psnr:.5f} (ref {c['psnr']:.5f})")
+    assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    assert abs(bpp - c["bpp"]) <= BPP_TOL * max(1.0, c["bpp"])
+    assert abs(psnr - c["psnr"]) <= PSNR_TOL_DB
+    assert n_ok >= 0.9 * n_str
+
+
+def test_batch_invariance_and_roundtrip_at_bench_size():
+    """Config 2 shape (256x256 crops): an image codes identically alone and inside a batch; decode(encode(x))
+    equals the encoder's own reconstruction of the latents (x_hat identical for B=1 and batch)."""
+    net = gpu_codec()
+    x = inputs(4, 256, 256, 21).cuda()
+    q = 0.5
+    out = net.compress(x, q, "point-based-std")
+    one = net.compress(x[2:3].contiguous(), q, "point-based-std")
+    for sl_b, sl_1 in zip(out["strings"][0], one["strings"][0]):
+        assert sl_b[2] == sl_1[0]
+    assert out["strings"][1][2] == one["strings"][1][0]
+    dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")["x_hat"]
+    dec1 = net.decompress(one["strings"], one["shape"], q, "point-based-std")["x_hat"]
+    assert torch.equal(dec[2], dec1[0])
+    assert dec.min().item() >= 0.0 and dec.max().item() <= 1.0
+    h = w = 16
+    k = int(32 * h * w)
+    for m in out["masks"]:
+        s = m.sum(dim=(1, 2, 3)).cpu()
+        assert ((s - 0.05 * k).abs() <= 2).all(), s      # top 5 % per image (ties may add a few)
+
+
+def test_quality_levels_monotone_bytes():
+    """More of the enhancement latent is coded as the mask level grows (train.py:293 level list, subset)."""
+    net = gpu_codec()
+    x = inputs(1, 128, 128, 5).cuda()
+    sizes = []
+    for q in (0, 0.05, 0.5, 2, 5, 10):
+        out = net.compress(x, q, "point-based-std")
+        sizes.append(sum(len(s) for sl in out["strings"][0] for s in sl))
+        dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")["x_hat"]
+        assert dec.shape == x.shape
+    assert sizes == sorted(sizes), sizes
+
+
+def test_error_behaviour():
+    net = gpu_codec()
+    with pytest.raises(ValueError):
+        net.compress(torch.rand(1, 3, 100, 128).cuda(), 0.5)
+    with pytest.raises(NotImplementedError):
+        net.compress(torch.rand(1, 3, 64, 64).cuda(), 0.5, mask_pol="random")
+    out = net.compress(torch.rand(1, 3, 64, 64).cuda(), 0.0, "point-based-std")
+    bad = [[s[0][:8]] for s in out["strings"][0]]
+    from progressivecodec_amd._lib import PcodecError
+    with pytest.raises(PcodecError):
+        net.decompress([bad, out["strings"][1]], out["shape"], 0.0, "point-based-std")

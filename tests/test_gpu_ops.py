@@ -1,0 +1,234 @@
+"""GPU parity of the individual device stages against the CPU oracle (bit-exact).
+
+Every call goes through the C ABI (include/pcodec.h) with raw device pointers.  The oracle
+(oracle/pc_oracle.c) evaluates the same fmaf chains / pc_math.h functions on the host.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import liboracle as lo  # noqa: E402  (the checker)
+
+
+def _lib():
+    from progressivecodec_amd._lib import check, lib
+    return lib(), check
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def P(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def pack(w, kind):
+    L, check = _lib()
+    if kind == 0:
+        co, ci, k, _ = w.shape
+    else:
+        ci, co, k, _ = w.shape
+    out = np.empty((k * k, ci, co), np.float32)
+    check(L.pc_pack_conv_weight(np.ascontiguousarray(w).ctypes.data_as(C.c_void_p), kind, co, ci, k,
+                                out.ctypes.data_as(C.c_void_p)))
+    return out
+
+
+def ref_conv(x, w, b, stride, act):
+    co, ci, k, _ = w.shape
+    pad = k // 2
+    B, H, W, _ = x.shape
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    taps = [(ky - pad, kx - pad) for ky in range(k) for kx in range(k)]
+    wt = np.ascontiguousarray(w.transpose(2, 3, 1, 0).reshape(k * k, ci, co))
+    acc = lo.conv_nhwc(x, wt, taps, stride, Ho, Wo) + b.reshape(1, 1, 1, -1)
+    return lo.unary(acc, "gelu") if act else acc
+
+
+def ref_deconv(x, w, b):
+    ci, co, _, _ = w.shape
+    B, H, W, _ = x.shape
+    out = np.zeros((B, 2 * H, 2 * W, co), np.float32)
+    for py in range(2):
+        for px in range(2):
+            kys, kxs = range(py, 5, 2), range(px, 5, 2)
+            taps = [((py + 2 - ky) // 2, (px + 2 - kx) // 2) for ky in kys for kx in kxs]
+            wt = np.ascontiguousarray(np.stack([w[:, :, ky, kx] for ky in kys for kx in kxs]))
+            lo.conv_nhwc(x, wt, taps, 1, H, W, out=out, ostride=(2, 2), ooff=(py, px))
+    return out + b.reshape(1, 1, 1, -1)
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, stride, act, tile
+    (2, 16, 16, 192, 192, 5, 2, 0, 0),
+    (1, 12, 20, 96, 96, 3, 1, 1, 0),
+    (2, 8, 8, 352, 224, 3, 1, 1, 0),     # cc stack head, N = 224 (tail of a 64-wide tile)
+    (2, 8, 8, 224, 176, 3, 1, 1, 0),     # N = 176 = 5.5 x 32
+    (2, 8, 8, 64, 32, 3, 1, 0, 0),       # N = 32
+    (3, 4, 4, 288, 256, 3, 2, 1, 0),
+    (1, 16, 16, 192, 576, 1, 1, 0, 0),
+    (2, 16, 16, 192, 192, 5, 2, 0, 1),   # forced 128x128
+    (2, 16, 16, 192, 192, 5, 2, 0, 2),   # forced 64x64
+    (2, 16, 16, 192, 192, 5, 2, 0, 3),   # forced 128x32
+    (1, 1, 1, 224, 192, 3, 2, 0, 0),     # M = 1 (64x64 image hyper-analysis tail)
+    (2, 32, 32, 3, 192, 5, 2, 0, 0),     # first layer: Cin = 3 element-wise gather path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bit_exact(case):
+    L, check = _lib()
+    B, H, W, ci, co, k, s, act, tile = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((co, ci, k, k)) * (2.0 / (ci * k * k)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    want = ref_conv(x, w, b, s, act)
+    xd, wd, bd = dev(x), dev(pack(w, 0)), dev(b)
+    out = torch.empty(want.shape, device="cuda", dtype=torch.float32)
+    check(L.pc_conv2d_nhwc(P(xd), B, H, W, ci, P(wd), P(bd), 0, co, k, s, act, tile, P(out), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), \
+        f"max abs diff {np.abs(got - want).max()} mismatches {(got != want).sum()}/{got.size}"
+
+
+@pytest.mark.parametrize("case", [(2, 4, 4, 320, 192), (1, 8, 8, 192, 192), (2, 8, 8, 192, 3)])
+def test_deconv_bit_exact(case):
+    L, check = _lib()
+    B, H, W, ci, co = case
+    rng = np.random.default_rng(5 + co)
+    x = rng.standard_normal((B, H, W, ci)).astype(np.float32)
+    w = (rng.standard_normal((ci, co, 5, 5)) * (8.0 / (ci * 25)) ** 0.5).astype(np.float32)
+    b = (rng.standard_normal(co) * 0.1).astype(np.float32)
+    want = ref_deconv(x, w, b)
+    xd, wd, bd = dev(x), dev(pack(w, 1)), dev(b)
+    out = torch.empty(want.shape, device="cuda", dtype=torch.float32)
+    check(L.pc_conv2d_nhwc(P(xd), B, H, W, ci, P(wd), P(bd), 1, co, 5, 2, 0, 0, P(out), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"max abs diff {np.abs(got - want).max()}"
+
+
+def test_deconv_matches_torch_semantics():
+    """The phase decomposition is ConvTranspose2d(5, s2, p2, op1) (models/utils.py:196) -- tolerance vs ATen."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, 6, 5, 32)).astype(np.float32)
+    w = (rng.standard_normal((32, 16, 5, 5)) * 0.1).astype(np.float32)
+    b = rng.standard_normal(16).astype(np.float32)
+    want = F.conv_transpose2d(torch.from_numpy(x).permute(0, 3, 1, 2), torch.from_numpy(w), torch.from_numpy(b),
+                              stride=2, padding=2, output_padding=1).permute(0, 2, 3, 1).numpy()
+    assert np.allclose(ref_deconv(x, w, b), want, atol=2e-5)
+
+
+@pytest.mark.parametrize("inverse", [0, 1])
+def test_gdn_bit_exact(inverse):
+    L, check = _lib()
+    rng = np.random.default_rng(3)
+    B, H, W, Cc = 2, 9, 7, 192
+    x = rng.standard_normal((B, H, W, Cc)).astype(np.float32)
+    beta = (1.0 + rng.random(Cc)).astype(np.float32)
+    gamma = (0.1 * np.eye(Cc) + 0.004 * np.abs(rng.standard_normal((Cc, Cc)))).astype(np.float32)
+    gt = np.ascontiguousarray(gamma.T)
+    norm = lo.conv_nhwc(x, gt.reshape(1, Cc, Cc), [(0, 0)], 1, H, W, square=True) + beta.reshape(1, 1, 1, -1)
+    want = x * lo.unary(norm, "sqrt" if inverse else "rsqrt")
+    out = torch.empty(want.shape, device="cuda", dtype=torch.float32)
+    xd, bd, gd = dev(x), dev(beta), dev(gt)
+    check(L.pc_gdn_nhwc(P(xd), B, H, W, Cc, P(bd), P(gd), inverse, P(out), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("case", [(2, 16, 16, 192, 8, 4), (2, 8, 8, 640, 4, 2), (1, 4, 12, 320, 4, 2), (1, 8, 24, 192, 8, 4)])
+def test_window_attention_bit_exact(case):
+    L, check = _lib()
+    B, H, W, Cc, ws, shift = case
+    rng = np.random.default_rng(Cc + ws)
+    qkv = rng.standard_normal((B, H, W, 3 * Cc)).astype(np.float32)
+    T = ws * ws
+    bias = (rng.standard_normal((8, T, T)) * 0.4).astype(np.float32)
+    want = lo.win_attention(qkv, bias, 8, ws, shift, np.float32((Cc // 8) ** -0.5))
+    out = torch.empty(want.shape, device="cuda", dtype=torch.float32)
+    qd, bd = dev(qkv), dev(bias)
+    check(L.pc_win_attention_nhwc(P(qd), P(bd), B, H, W, Cc, 8, ws, shift, P(out), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"max abs diff {np.abs(got - want).max()}"
+
+
+@pytest.mark.parametrize("n_hw,pr", [(16, 0.5), (256, 0.05), (256, 5.0), (1536, 0.75), (4096, 9.99), (64, 2.0)])
+def test_quantile_threshold_bit_exact(n_hw, pr):
+    L, check = _lib()
+    rng = np.random.default_rng(n_hw)
+    B = 3
+    scale = (0.6 + 0.7 * rng.standard_normal((B, n_hw, 32))).astype(np.float32)
+    scale[1] = np.round(scale[1] * 4) / 4                      # ties
+    q = np.float32(1.0 - pr * 0.1)
+    want = np.array([lo.quantile(scale[b], q) for b in range(B)], np.float32)
+    thr = torch.empty(B, device="cuda", dtype=torch.float32)
+    sd = dev(scale)
+    check(L.pc_mask_quantile_threshold(P(sd), 32, B, n_hw, 32, q, P(thr), None))
+    torch.cuda.synchronize()
+    got = thr.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (got, want)
+    # and against ATen itself
+    t = torch.quantile(torch.from_numpy(scale.reshape(B, -1)), float(1.0 - pr * 0.1), dim=1).numpy()
+    assert np.array_equal(got, t)
+
+
+@pytest.mark.parametrize("hw,mode,delta", [(16, 0, 0), (256, 1, 1), (100, 1, 1), (256, 2, 1), (1024, 3, 1)])
+def test_gc_prep_encode_and_decode_bit_exact(hw, mode, delta):
+    from tests.util import tables_npz
+    L, check = _lib()
+    rng = np.random.default_rng(hw + mode)
+    B = 2
+    table = tables_npz()["scale_table"]
+    scale = (0.6 + 0.7 * rng.standard_normal((B, hw, 32))).astype(np.float32)
+    scale[0, 0, :4] = table[[3, 10, 20, 62]]                  # exactly on table entries (<= compare)
+    mu = rng.standard_normal((B, hw, 32)).astype(np.float32)
+    y = (rng.standard_normal((B, hw, 64)) * 2).astype(np.float32)
+    y[0, 1, 32:40] = mu[0, 1, :8] + np.array([0.5, 1.5, 2.5, -0.5, -1.5, -2.5, 3.5, 4.5], np.float32)   # ties to even
+    thr = np.array([lo.quantile(scale[b], np.float32(0.95)) for b in range(B)], np.float32)
+    # oracle
+    if mode == 1:
+        m = (scale >= thr.reshape(B, 1, 1)).astype(np.float32)
+    elif mode == 2:
+        m = np.ones_like(scale)
+    elif mode == 3:
+        m = np.zeros_like(scale)
+    else:
+        m = None
+    ysl = y[..., 32:] - y[..., :32] if delta else y[..., 32:]
+    sm = scale if m is None else scale * m
+    idx_w = lo.build_indexes(sm, table, 0.11)
+    v = ysl - mu
+    sym_w = lo.quantize(v if m is None else v * m)
+    yhat_w = sym_w.astype(np.float32) + mu
+    tr = lambda a: np.ascontiguousarray(a.transpose(0, 2, 1))            # [B][HW][32] -> [B][32][HW]
+    sd_, md, yd, td, tabd = dev(scale), dev(mu), dev(y), dev(thr), dev(table)
+    sym = torch.empty((B, 32, hw), device="cuda", dtype=torch.int32)
+    idx = torch.empty_like(sym)
+    msk = torch.empty((B, 32, hw), device="cuda", dtype=torch.float32)
+    yhat = torch.zeros((B, hw, 32), device="cuda", dtype=torch.float32)
+    ybase = C.c_void_p(yd.data_ptr()) if delta else None
+    check(L.pc_gc_prep_encode(P(sd_), 32, P(md), 32, C.c_void_p(yd.data_ptr() + 32 * 4), 64, ybase, 64, P(td), mode, B, hw,
+                              P(tabd), 64, 0.11, P(sym), P(idx), P(msk), P(yhat), 32, None))
+    idx2 = torch.empty_like(idx)
+    check(L.pc_gc_prep_decode_index(P(sd_), 32, P(td), mode, B, hw, P(tabd), 64, 0.11, P(idx2), None, None))
+    yhat2 = torch.zeros_like(yhat)
+    check(L.pc_gc_dequantize(P(sym), P(md), 32, B, hw, P(yhat2), 32, None))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), tr(idx_w))
+    assert np.array_equal(idx2.cpu().numpy(), tr(idx_w))
+    assert np.array_equal(sym.cpu().numpy(), tr(sym_w))
+    if m is not None:
+        assert np.array_equal(msk.cpu().numpy(), tr(m))
+    assert np.array_equal(yhat.cpu().numpy().view(np.uint32), yhat_w.view(np.uint32))
+    assert np.array_equal(yhat2.cpu().numpy().view(np.uint32), yhat_w.view(np.uint32))
