@@ -330,7 +330,7 @@ int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H
     PCCHK(ru(st, w.a[2], a1, C, B, H, W, t1, t2, a0));                  // a in a0
     // branch b: window attention, three residual units, 1x1
     PCCHK(conv(st, w.qkv, {{x, C, C}}, B, H, W, 1, qkv, 3 * C, PC_EPI_NONE));
-    PCCHK(pc_win_attention_launch(qkv, w.bias, B, H, W, C, HEADS, w.ws, w.shift, 1.0f / std::sqrt((float)(C / HEADS)), a1, st));
+    PCCHK(pc_win_attention_launch(qkv, w.bias, B, H, W, C, HEADS, w.ws, w.shift, (float)std::pow((double)(C / HEADS), -0.5), a1, st));
     PCCHK(conv(st, w.proj, {{a1, C, C}}, B, H, W, 1, o, C, PC_EPI_RES, x, C));     // shortcut + proj(attn)
     PCCHK(ru(st, w.b[0], o, C, B, H, W, t1, t2, b1));
     PCCHK(ru(st, w.b[1], b1, C, B, H, W, t1, t2, o));
@@ -533,7 +533,7 @@ extern "C" int pc_win_attention_nhwc(const float* qkv, const float* bias, int B,
                                      int shift, float* out, void* stream)
 {
     if (!qkv || !bias || !out || heads <= 0) return PC_ERR_ARG;
-    return pc_win_attention_launch(qkv, bias, B, H, W, C, heads, window, shift, 1.0f / std::sqrt((float)(C / heads)), out,
+    return pc_win_attention_launch(qkv, bias, B, H, W, C, heads, window, shift, (float)std::pow((double)(C / heads), -0.5) /* win_attention.py:57: head_dim ** -0.5 in Python double, applied as a float32 scalar */, out,
                                    (hipStream_t)stream);
 }
 
