@@ -165,6 +165,12 @@ PC_API int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, con
                                const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
                                double quality, int mask_pol, float* x_hat, void* stream);
 
+/* Measurement aid (bench.py roofline leg): while profiling is on, every launch of the MFMA convolution kernel made by
+ * compress()/decompress() is bracketed by HIP events on the call's stream; _end returns the launch count, the summed
+ * event time and the algorithmic FLOPs (2*M*N*K per launch, no padding counted). */
+PC_API int pc_codec_profile_begin(pc_codec* c);
+PC_API int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_ms, double* total_flops);
+
 /* Debug/test taps: copy an internal device tensor of the last call to host ("y", "z", "latent_means", ...). */
 PC_API int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap_floats, size_t* n_floats);
 PC_API int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* host_out, size_t cap, size_t* n);

@@ -17,6 +17,17 @@ def build(force=False):
     return _SO
 
 
+def _host_threads(cap=16):
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
 _lib = None
 _i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
 _u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
@@ -28,6 +39,8 @@ def lib():
     global _lib
     if _lib is None:
         L = C.CDLL(build())
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_num_threads(_host_threads())
         L.orc_rans_encode.argtypes = [_i32p, _i32p, C.c_int64, _i32p, C.c_int, _i32p, _i32p, C.c_int,
                                       _u8p, C.c_int64, C.POINTER(C.c_int64)]
         L.orc_rans_decode.argtypes = [_u8p, C.c_int64, _i32p, C.c_int64, _i32p, C.c_int, _i32p, _i32p, C.c_int, _i32p]

@@ -28,7 +28,11 @@
 
 #include "../include/pc_math.h"
 
+#include <omp.h>
+
 #define ORC_API __attribute__((visibility("default")))
+
+ORC_API void orc_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 
 /* ------------------------------------------------------------------------- */
 /* rANS (ryg rans64, 16-bit precision, 4-bit bypass)                          */

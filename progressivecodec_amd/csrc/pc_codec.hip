@@ -16,6 +16,7 @@
 #include <new>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -26,6 +27,8 @@
 #include "pc_host.h"
 
 static thread_local int g_last_hip = 0;
+struct pc_codec;
+static thread_local pc_codec* g_prof = nullptr;   // codec whose conv launches are being timed (profile mode)
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { g_last_hip = (int)_e; return PC_ERR_HIP; } } while (0)
 #define PCCHK(expr) do { int _r = (expr); if (_r != PC_OK) return _r; } while (0)
 
@@ -80,6 +83,13 @@ struct pc_codec {
     std::vector<std::vector<uint8_t>> y_strings;  // [slice*B + b]
     std::vector<std::vector<uint8_t>> z_strings;  // [b]
     int n_threads = 0;
+    // optional per-launch profiling of the MFMA conv family (bench.py roofline leg)
+    bool profile = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+    double prof_flops = 0.0;
+    struct ProfRec { int M, N, K, nphase, epi; double flops; };
+    std::vector<ProfRec> prof_rec;
     // last-call geometry for taps
     int last_B = 0, last_h16 = 0, last_w16 = 0;
 
@@ -99,6 +109,27 @@ struct pc_codec {
 };
 
 namespace {
+
+// conv launch, optionally bracketed by HIP events on the launch stream (profile mode)
+int launch_conv(const pc_conv_params& q, hipStream_t st)
+{
+    pc_codec* c = g_prof;
+    if (!c) return pc_conv_launch(q, st);
+    if (c->ev_used + 2 > c->ev.size()) {
+        const size_t old = c->ev.size();
+        c->ev.resize(old + 512);
+        for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+    }
+    long taps = 0;
+    for (int ph = 0; ph < q.nphase; ++ph) taps += q.ntap[ph];
+    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin;
+    c->prof_flops += fl;
+    c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl});
+    HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
+    const int r = pc_conv_launch(q, st);
+    HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
+    return r;
+}
 
 // ------------------------------------------------------------------------------------------ weights
 const HostTensor* find(const pc_codec* c, const std::string& k, int dtype, std::initializer_list<int64_t> shape)
@@ -284,7 +315,7 @@ int conv(hipStream_t st, const ConvW& w, std::initializer_list<Seg> segs, int B,
     q.pixel_shuffle = pixel_shuffle ? 1 : 0;
     if (pixel_shuffle) { q.outH *= 2; q.outW *= 2; }
     q.out_sc = 1; q.out_sx = ldo; q.out_sy = (int64_t)q.outW * ldo; q.out_sb = (int64_t)q.outH * q.outW * ldo;
-    return pc_conv_launch(q, st);
+    return launch_conv(q, st);
 }
 
 int gdn(hipStream_t st, const GdnW& g, const float* x, int B, int H, int W, bool inverse, float* out)
@@ -298,7 +329,7 @@ int gdn(hipStream_t st, const GdnW& g, const float* x, int B, int H, int W, bool
     q.Ho = H; q.Wo = W; q.outH = H; q.outW = W; q.M = B * H * W;
     q.out = out; q.out_sc = 1; q.out_sx = g.C; q.out_sy = (int64_t)W * g.C; q.out_sb = (int64_t)H * W * g.C;
     q.epi = inverse ? PC_EPI_IGDN : PC_EPI_GDN; q.aux0 = x; q.ld0 = g.C;
-    return pc_conv_launch(q, st);
+    return launch_conv(q, st);
 }
 
 // ResidualUnit (layers/layers.py:38-57): x -> gelu(conv1x1) -> gelu(conv3x3) -> conv1x1 + x -> gelu
@@ -390,7 +421,7 @@ int g_a(pc_codec* c, hipStream_t st, const float* x, int B, int H, int W, float*
         q.w = c->ga0.w; q.bias = c->ga0.b; q.Cout = NCH;
         q.Ho = H / 2; q.Wo = W / 2; q.outH = q.Ho; q.outW = q.Wo; q.M = B * q.Ho * q.Wo;
         q.out = t0; q.out_sc = 1; q.out_sx = NCH; q.out_sy = (int64_t)q.Wo * NCH; q.out_sb = (int64_t)q.Ho * q.Wo * NCH;
-        PCCHK(pc_conv_launch(q, st));
+        PCCHK(launch_conv(q, st));
     }
     PCCHK(gdn(st, c->ga1, t0, B, H / 2, W / 2, false, t1));
     PCCHK(conv(st, c->ga2, {{t1, NCH, NCH}}, B, H / 2, W / 2, 2, t2, NCH, PC_EPI_NONE));
@@ -429,7 +460,7 @@ int g_s(pc_codec* c, hipStream_t st, const GsW& g, const float* yhat, int B, int
         q.Ho = H; q.Wo = W; q.outH = 2 * H; q.outW = 2 * W; q.M = B * H * W;
         q.out = x_hat; q.out_sx = 1; q.out_sy = q.outW; q.out_sc = (int64_t)q.outH * q.outW; q.out_sb = 3 * q.out_sc;
         q.epi = PC_EPI_CLAMP01;
-        PCCHK(pc_conv_launch(q, st));
+        PCCHK(launch_conv(q, st));
     }
     return PC_OK;
 }
@@ -601,6 +632,7 @@ extern "C" void pc_codec_destroy(pc_codec* c)
     (void)hipSetDevice(c->device);
     for (void* p : c->weight_allocs) (void)hipFree(p);
     for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     if (c->h_sym) (void)hipHostFree(c->h_sym);
     if (c->h_idx) (void)hipHostFree(c->h_idx);
     delete c;
@@ -726,6 +758,7 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     if (c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    g_prof = c->profile ? c : nullptr;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
     const int n_slices = quality <= 0 ? NS0 : 2 * NS0;
@@ -827,6 +860,7 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
     if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    g_prof = c->profile ? c : nullptr;
     const int h = 4 * zh, w = 4 * zw, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
@@ -922,4 +956,39 @@ extern "C" int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out,
 extern "C" int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* host_out, size_t cap, size_t* n)
 {
     return pc_codec_read_tap(c, name, reinterpret_cast<float*>(host_out), cap, n);
+}
+
+extern "C" int pc_codec_profile_begin(pc_codec* c)
+{
+    if (!c) return PC_ERR_ARG;
+    c->profile = true; c->ev_used = 0; c->prof_flops = 0.0; c->prof_rec.clear();
+    return PC_OK;
+}
+
+extern "C" int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_ms, double* total_flops)
+{
+    if (!c || !n_launches || !total_ms || !total_flops) return PC_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+        float t = 0.0f;
+        HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+        ms += t;
+    }
+    if (const char* path = std::getenv("PC_PROFILE_CSV")) {      // per-launch shapes and times, for tuning
+        if (FILE* f = std::fopen(path, "w")) {
+            std::fprintf(f, "i,M,N,K,nphase,epi,gflop,us,tflops\n");
+            for (size_t i = 0; i + 1 < c->ev_used && i / 2 < c->prof_rec.size(); i += 2) {
+                float t = 0.0f;
+                (void)hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
+                const auto& r = c->prof_rec[i / 2];
+                std::fprintf(f, "%zu,%d,%d,%d,%d,%d,%.3f,%.1f,%.2f\n", i / 2, r.M, r.N, r.K, r.nphase, r.epi, r.flops / 1e9, t * 1e3, r.flops / (t * 1e-3) / 1e12);
+            }
+            std::fclose(f);
+        }
+    }
+    *n_launches = (int64_t)(c->ev_used / 2); *total_ms = ms; *total_flops = c->prof_flops;
+    c->profile = false; c->ev_used = 0; g_prof = nullptr;
+    return PC_OK;
 }

@@ -8,6 +8,7 @@
 #include <atomic>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <mutex>
@@ -202,9 +203,11 @@ struct ThreadPool::Impl {
 ThreadPool::ThreadPool(int n_threads) : impl_(new Impl)
 {
     if (n_threads <= 0) {
+        // one codec process serves one GPU; its host share on an 8-GPU node is ~16 cores
         unsigned hc = std::thread::hardware_concurrency();
         n_threads = hc ? (int)hc : 4;
-        if (n_threads > 32) n_threads = 32;
+        if (const char* e = std::getenv("PC_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n_threads = v; }
+        else if (n_threads > 16) n_threads = 16;
     }
     n_ = n_threads;
     for (int t = 0; t < n_threads - 1; ++t) {
