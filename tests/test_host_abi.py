@@ -1,0 +1,143 @@
+"""CPU-side tests of the product library: it loads, exports every symbol include/pcodec.h declares,
+and its host entry points (entropy coder, pmf->CDF) reproduce the reference's known answers.
+No GPU compute is called here."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from progressivecodec_amd import entropy
+from progressivecodec_amd._lib import EXPORTS, PcodecError, lib
+from tests.util import GOLD, ROOT, tables_npz
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "pcodec.h")).read()
+    declared = set(re.findall(r"PC_API\s+[\w\s\*]+?\b(pc_\w+)\s*\(", hdr))
+    assert declared == set(EXPORTS), declared ^ set(EXPORTS)
+    L = lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.pc_version()
+
+
+def gc_tables():
+    t = tables_npz()
+    return entropy.CdfTables(t["gc_cdf"], t["gc_len"], t["gc_off"])
+
+
+def test_rans_known_answers_from_reference():
+    for k in json.load(open(os.path.join(GOLD, "kat_rans.json"))):
+        if k.get("table") == "gc":
+            t = gc_tables()
+        else:
+            t = entropy._tables_from_lists(k["cdfs"], k["sizes"], k["offsets"])
+        enc = entropy.rans_encode(k["symbols"], k["indexes"], t)
+        assert enc.hex() == k["encoded_hex"], k["name"]
+        assert len(enc) % 4 == 0 and len(enc) >= 8
+        dec = entropy.rans_decode(bytes.fromhex(k["encoded_hex"]), k["indexes"], t)
+        assert dec.tolist() == k["symbols"], k["name"]
+
+
+def test_drop_in_ans_surface():
+    """compressai.ans.RansEncoder / RansDecoder call signature (rans_interface.cpp:352-372)."""
+    s = entropy.RansEncoder().encode_with_indexes([0, 1, -1, 0, 7, -4], [0] * 6, [[0, 8192, 57344, 61440, 65536]], [5], [-1])
+    assert s.hex() == "a141ad217f1cc771"
+    assert entropy.RansDecoder().decode_with_indexes(s, [0] * 6, [[0, 8192, 57344, 61440, 65536]], [5], [-1]) == [0, 1, -1, 0, 7, -4]
+
+
+def test_rans_matches_oracle_on_random_streams_and_batches():
+    from oracle import liboracle as lo
+    t = gc_tables()
+    ot = lo.Tables(t.cdf, t.length, t.offset)
+    rng = np.random.default_rng(1)
+    st = tables_npz()["scale_table"]
+    n_streams, n = 9, 3000
+    idx = rng.integers(0, 64, (n_streams, n)).astype(np.int32)
+    sym = np.rint(rng.standard_normal((n_streams, n)) * st[idx] * 1.3).astype(np.int32)
+    sym[0, ::50] = rng.integers(-5000, 5000, sym[0, ::50].size)
+    L = lib()
+    stride = L.pc_rans_bound(n)
+    out = np.zeros((n_streams, stride), np.uint8)
+    lens = np.zeros(n_streams, np.uint64)
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = L.pc_rans_encode_batch(P(sym), P(idx), n_streams, n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(out),
+                                stride, P(lens), 0)
+    assert rc == 0
+    enc = [out[i, : int(lens[i])].tobytes() for i in range(n_streams)]
+    for i in range(n_streams):
+        assert enc[i] == lo.rans_encode(sym[i], idx[i], ot)
+    ptrs = (C.c_char_p * n_streams)(*enc)
+    ln = (C.c_size_t * n_streams)(*[len(e) for e in enc])
+    dec = np.zeros((n_streams, n), np.int32)
+    assert L.pc_rans_decode_batch(ptrs, ln, n_streams, P(idx), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec), 0) == 0
+    assert np.array_equal(dec, sym)
+
+
+def test_rans_edge_cases_and_errors():
+    t = gc_tables()
+    # empty input: the reference asserts / UB (rans_interface.cpp:170-172); we emit the 8-byte flush of the initial state
+    e = entropy.rans_encode([], [], t)
+    assert len(e) == 8 and entropy.rans_decode(e, [], t).size == 0
+    # n = 1
+    e1 = entropy.rans_encode([3], [10], t)
+    assert entropy.rans_decode(e1, [10], t).tolist() == [3]
+    with pytest.raises(PcodecError) as ei:
+        entropy.rans_encode([0], [64], t)
+    assert ei.value.code == -2
+    with pytest.raises(PcodecError) as ei:
+        entropy.rans_decode(b"\x00" * 4, [0], t)
+    assert ei.value.code == -4
+    big = entropy.rans_encode(np.arange(-3000, 3000), np.zeros(6000, np.int32), t)    # all bypass at index 0
+    assert np.array_equal(entropy.rans_decode(big, np.zeros(6000, np.int32), t), np.arange(-3000, 3000))
+    with pytest.raises(PcodecError) as ei:
+        entropy.rans_decode(big[: len(big) // 2], np.zeros(6000, np.int32), t)
+    assert ei.value.code == -4
+
+
+def test_pmf_to_quantized_cdf_known_answers():
+    t = tables_npz()
+    for key in [k[4:] for k in t if k.startswith("pmf_")]:
+        got = np.array(entropy.pmf_to_quantized_cdf(t["pmf_" + key], 16), np.uint32)
+        assert np.array_equal(got, t["cdf_" + key]), key
+    assert entropy.pmf_to_quantized_cdf([0.1, 0.7, 0.15, 0.05], 16) == [0, 6554, 52429, 62259, 65536]
+    with pytest.raises(PcodecError):
+        entropy.pmf_to_quantized_cdf([0.0, 0.0], 16)
+
+
+def test_tables_rebuilt_by_update_equal_the_reference_tables():
+    """GaussianConditional.update / EntropyBottleneck.update restated (entropy.py) == the reference's buffers."""
+    from progressivecodec_amd.synth import synthetic_state_dict
+    sd = {k: v.numpy() for k, v in synthetic_state_dict().items()}
+    t = tables_npz()
+    g = entropy.gaussian_conditional_tables(sd["gaussian_conditional.scale_table"])
+    assert np.array_equal(g.cdf, t["gc_cdf"]) and np.array_equal(g.length, t["gc_len"]) and np.array_equal(g.offset, t["gc_off"])
+    e = entropy.entropy_bottleneck_tables(sd)
+    assert np.array_equal(e.cdf, t["eb_cdf"]) and np.array_equal(e.length, t["eb_len"]) and np.array_equal(e.offset, t["eb_off"])
+    assert g.cdf.shape == (64, 3133) and g.length.min() == 5 and g.length.max() == 3133 and g.offset.min() == -1565
+
+
+def test_codec_needs_a_gpu_and_fails_loudly_without_one():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib().pc_codec_create(C.byref(h), 0) == -6          # PC_ERR_HIP: no device, no CPU fallback
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    with pytest.raises((PcodecError, RuntimeError)):
+        ChannelProgresssiveWACNN(device="cuda:0")
+    with pytest.raises(RuntimeError):
+        ChannelProgresssiveWACNN(device="cpu")
+
+
+def test_arch_spec_matches_reference_state_dict_layout():
+    from progressivecodec_amd.arch import param_spec
+    spec = param_spec()
+    assert len(spec) == 1019
+    n_params = sum(int(np.prod(s)) for k, (s, d, kind) in spec.items()
+                   if kind not in ("table", "pedestal", "beta_bound", "gamma_bound", "relpos_index", "eb_target",
+                                   "likelihood_bound", "scale_bound", "scale_table"))
+    assert n_params == 152137398                                 # authors' log, SURVEY.md section 6
