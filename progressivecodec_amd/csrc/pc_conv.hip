@@ -24,6 +24,7 @@
 // ([k][m] / [k][n]) so every ds_read_b32 of an MFMA operand is bank-conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "../../include/pc_math.h"
 #include "pc_device.h"
@@ -250,14 +251,210 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+
+// ------------------------------------------------------------------------------------------
+// Main kernel (all layers with Cin % 16 == 0).  Differences from the element-gather kernel above:
+//  * K-chunk BK = 16 or 32 channels of ONE tap and ONE segment (wave-uniform iterator: tap,
+//    segment, channel live in SGPRs, parameters come through scalar loads); a segment tail shorter
+//    than BK is zero-filled (zeros leave the fmaf chain unchanged);
+//  * two chunks in flight in registers (prefetch distance 2) on top of the LDS double buffer: a
+//    global-load round trip (~1.1 us measured per chunk on the M = 8192 slice-chain GEMMs, which
+//    have <= 2 blocks per CU) is then covered by two MFMA phases instead of one;
+//  * register budget kept low (<= 128 VGPRs) because occupancy is what hides the per-chunk barrier.
+// The fmaf chain per output element is unchanged: chunks, and k inside a chunk, ascend.
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+__global__ __launch_bounds__(256) void conv_igemm2_kernel(const pc_conv_params p)
+{
+    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
+    constexpr int LDA = BM + 1, LDB = BN + 4;
+    constexpr int KQ = BK / 4;                        // 16-byte k-quads per A row
+    constexpr int ROWS_PER_PASS = 256 / KQ;
+    constexpr int AI = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // A float4 per thread per chunk
+    constexpr int BQ = BN / 4;                        // float4 per B row
+    constexpr int BROWS_PER_PASS = 256 / BQ;
+    constexpr int BI = (BK + BROWS_PER_PASS - 1) / BROWS_PER_PASS;
+    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
+    __shared__ float smem[2 * BK * (LDA + LDB)];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int phase = blockIdx.z;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int T = p.ntap[phase];
+    const int HoWo = p.Ho * p.Wo;
+
+    int chunks_per_tap = 0;
+    for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
+    const int nchunks = T * chunks_per_tap;
+
+    // ---- A: fixed rows, k-quad column kq
+    const int kq = tid % KQ;
+    const int arow0 = tid / KQ;
+    int a_iy0[AI], a_ix0[AI];
+    int64_t a_boff[AI];
+    bool a_ok[AI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+        const int row = arow0 + i * ROWS_PER_PASS;
+        const int m = m0 + row;
+        a_ok[i] = (row < BM) && (m < p.M);
+        const int mm = a_ok[i] ? m : 0;
+        const int b = mm / HoWo, r = mm - b * HoWo;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_iy0[i] = oy * p.stride;
+        a_ix0[i] = ox * p.stride;
+        a_boff[i] = (int64_t)b * p.H * p.W;
+    }
+    // ---- B: rows bk0 + i * BROWS_PER_PASS, columns b_n
+    const int b_n = (tid % BQ) * 4;
+    const int bk0 = tid / BQ;
+    const bool b_nok = n0 + b_n < p.Cout;
+    const bool b_full = n0 + b_n + 3 < p.Cout;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // wave-uniform chunk iterator
+    int it_t = 0, it_s = 0, it_c = 0, it_cg = 0, it_sbase = 0;
+
+    auto load_chunk = [&](float4 (&ra)[AI], float4 (&rb)[BI]) {
+        const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
+        const int nch = p.seg[it_s].nch;
+        const float* sp = p.seg[it_s].ptr + it_c + 4 * kq;
+        const int sld = p.seg[it_s].ld;
+        const bool kq_ok = it_c + 4 * kq < nch;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (kq_ok && a_ok[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
+                v = *reinterpret_cast<const float4*>(sp + (a_boff[i] + (int64_t)iy * p.W + ix) * sld);
+            if (p.square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
+            ra[i] = v;
+        }
+        const float* wrow = p.w + ((int64_t)p.wtap[phase][it_t] * p.Cin + it_cg) * p.Cout + n0 + b_n;
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int k = bk0 + i * BROWS_PER_PASS;
+            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < BK && it_c + k < nch && b_nok) {
+                const float* wp = wrow + (int64_t)k * p.Cout;
+                if (b_full) w = *reinterpret_cast<const float4*>(wp);
+                else { w.x = wp[0]; if (n0 + b_n + 1 < p.Cout) w.y = wp[1]; if (n0 + b_n + 2 < p.Cout) w.z = wp[2]; }
+            }
+            rb[i] = w;
+        }
+        it_c += BK; it_cg += BK;
+        if (it_c >= nch) {
+            it_sbase += nch; it_c = 0; it_cg = it_sbase; ++it_s;
+            if (it_s >= p.nseg) { it_s = 0; it_sbase = 0; it_cg = 0; ++it_t; }
+        }
+    };
+
+    auto store_chunk = [&](int buf, const float4 (&ra)[AI], const float4 (&rb)[BI]) {
+        float* a = As + buf * BK * LDA;
+        float* b = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < AI; ++i) {
+            const int row = arow0 + i * ROWS_PER_PASS;
+            if (row < BM) {
+                a[(kq * 4 + 0) * LDA + row] = ra[i].x;
+                a[(kq * 4 + 1) * LDA + row] = ra[i].y;
+                a[(kq * 4 + 2) * LDA + row] = ra[i].z;
+                a[(kq * 4 + 3) * LDA + row] = ra[i].w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BI; ++i) {
+            const int k = bk0 + i * BROWS_PER_PASS;
+            if (k < BK) *reinterpret_cast<float4*>(b + k * LDB + b_n) = rb[i];
+        }
+    };
+
+    const int half = lane >> 5, l31 = lane & 31;
+    auto compute = [&](int buf) {
+        const float* a = As + buf * BK * LDA + wm * (TM * 32) + l31;
+        const float* b = Bs + buf * BK * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = a[(kk + half) * LDA + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = b[(kk + half) * LDB + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    float4 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
+    load_chunk(ra0, rb0);
+    if (nchunks > 1) load_chunk(ra1, rb1);
+    store_chunk(0, ra0, rb0);
+    __syncthreads();
+    for (int c = 0;;) {
+        if (c + 2 < nchunks) load_chunk(ra0, rb0);
+        compute(0);
+        if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
+        __syncthreads();
+        if (++c >= nchunks) break;
+        if (c + 2 < nchunks) load_chunk(ra1, rb1);
+        compute(1);
+        if (c + 1 < nchunks) store_chunk(0, ra0, rb0);
+        __syncthreads();
+        if (++c >= nchunks) break;
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = m0 + wm * (TM * 32) + i * 32 + row;
+            if (m >= p.M) continue;
+            const int b = m / HoWo, rr = m - b * HoWo;
+            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+            int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n >= p.Cout) continue;
+                float v = acc[i][j][r];
+                if (p.bias) v = v + p.bias[n];
+                int nn = n, YY = Y, XX = X;
+                if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
+                const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
+                v = epilogue_value(p, v, pix, nn);
+                p.out[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
+hipError_t launch_cfg2(const pc_conv_params& p, hipStream_t stream)
+{
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.nphase);
+    hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, WAVES_M, WAVES_N, BK>), grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALLC>
 hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
 {
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.nphase);
-    if (p.smallc)
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, true>), grid, dim3(256), 0, stream, p);
-    else
-        hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WAVES_M, WAVES_N, SMALLC>), grid, dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -281,21 +478,31 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         if (p.ntap[ph] < 1 || p.ntap[ph] > PC_MAX_TAP) return PC_ERR_ARG;
     if (p.pixel_shuffle && (p.Cout % 4)) return PC_ERR_ARG;
 
+    // Tile / K-loop selection (measured on MI355X, tools/conv_tune.py, profiles/r01_*):
+    //  * 64x64 block tiles win everywhere except the 3-channel output layer;
+    //  * with >= 4 blocks per CU the low-register BK=16 loop is fastest (occupancy hides the per-chunk
+    //    barrier); with fewer blocks (the M = 8192 slice-chain GEMMs) the BK=32 / prefetch-distance-2 loop is.
     int cfg = p.tile_cfg;
-    if (cfg == PC_TILE_AUTO) {
-        // heuristic: the largest tile that still yields >= 2 waves per SIMD (2048 waves), N-tail aware
-        const long tiles32 = (long)((p.M + 31) / 32) * ((p.Cout + 31) / 32) * p.nphase;
-        if (p.Cout <= 32) cfg = PC_TILE_128x32;
-        else if (tiles32 >= 4L * 2048 * 2 && p.Cout % 128 == 0) cfg = PC_TILE_128x128;
-        else if (p.Cout % 64 == 0 || p.Cout > 256) cfg = PC_TILE_64x64;
-        else cfg = PC_TILE_128x32;
-    }
+    static const int impl_env = [] { const char* v = std::getenv("PC_CONV_IMPL"); return v ? std::atoi(v) : 0; }();
+    if (cfg == PC_TILE_AUTO) cfg = (p.Cout <= 4) ? PC_TILE_128x32 : PC_TILE_64x64;
+    const int bm = cfg == PC_TILE_64x64 ? 64 : 128, bn = cfg == PC_TILE_128x128 ? 128 : (cfg == PC_TILE_64x64 ? 64 : 32);
+    const long blocks = (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.nphase;
+    int impl = impl_env ? impl_env : (blocks >= 1024 ? 1 : 2);
     hipError_t e;
-    switch (cfg) {
-    case PC_TILE_128x128: e = launch_cfg<128, 128, 2, 2>(p, stream); break;
-    case PC_TILE_64x64: e = launch_cfg<64, 64, 2, 2>(p, stream); break;
-    case PC_TILE_128x32: e = launch_cfg<128, 32, 4, 1>(p, stream); break;
-    default: return PC_ERR_ARG;
+    if (p.smallc || impl == 1) {
+        switch (cfg) {
+        case PC_TILE_128x128: e = p.smallc ? launch_cfg<128, 128, 2, 2, true>(p, stream) : launch_cfg<128, 128, 2, 2, false>(p, stream); break;
+        case PC_TILE_64x64: e = p.smallc ? launch_cfg<64, 64, 2, 2, true>(p, stream) : launch_cfg<64, 64, 2, 2, false>(p, stream); break;
+        case PC_TILE_128x32: e = p.smallc ? launch_cfg<128, 32, 4, 1, true>(p, stream) : launch_cfg<128, 32, 4, 1, false>(p, stream); break;
+        default: return PC_ERR_ARG;
+        }
+    } else {
+        switch (cfg) {
+        case PC_TILE_128x128: e = launch_cfg2<128, 128, 2, 2, 32>(p, stream); break;
+        case PC_TILE_64x64: e = launch_cfg2<64, 64, 2, 2, 32>(p, stream); break;
+        case PC_TILE_128x32: e = launch_cfg2<128, 32, 4, 1, 32>(p, stream); break;
+        default: return PC_ERR_ARG;
+        }
     }
     return e == hipSuccess ? PC_OK : PC_ERR_HIP;
 }

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the MFMA conv kernel through the C ABI (pc_conv2d_nhwc) on representative layer shapes.
+usage: python tools/conv_tune.py [tile_cfg ...]     env PC_CONV_IMPL=1|2 selects the K-loop implementation."""
+import ctypes as C
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from progressivecodec_amd._lib import check, lib
+
+SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
+    ("stack_L1", 32, 16, 16, 512, 224, 3, 1),
+    ("stack_L2", 32, 16, 16, 224, 176, 3, 1),
+    ("stack_L3", 32, 16, 16, 176, 128, 3, 1),
+    ("stack_L4", 32, 16, 16, 128, 64, 3, 1),
+    ("stack_L5", 32, 16, 16, 64, 32, 3, 1),
+    ("ga_conv2", 32, 128, 128, 192, 192, 5, 2),
+    ("ru_3x3", 32, 64, 64, 96, 96, 3, 1),
+    ("ru_1x1", 32, 64, 64, 96, 192, 1, 1),
+    ("gdn_like", 32, 128, 128, 192, 192, 1, 1),
+    ("ga_conv4", 32, 32, 32, 192, 640, 5, 2),
+]
+
+
+def main():
+    cfgs = [int(a) for a in sys.argv[1:]] or [0]
+    L = lib()
+    rng = np.random.default_rng(0)
+    for name, B, H, W, ci, co, k, s in SHAPES:
+        x = torch.from_numpy(rng.standard_normal((B, H, W, ci)).astype(np.float32)).cuda()
+        w = torch.from_numpy((rng.standard_normal((k * k, ci, co)) * 0.05).astype(np.float32)).cuda()
+        b = torch.zeros(co, device="cuda")
+        Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        out = torch.empty((B, Ho, Wo, co), device="cuda")
+        flops = 2.0 * B * Ho * Wo * co * k * k * ci
+        P = lambda t: C.c_void_p(t.data_ptr())
+        for cfg in cfgs:
+            def run():
+                check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), 0, co, k, s, 0, cfg, P(out), None))
+            try:
+                run()
+            except Exception as e:
+                print(f"{name:10s} cfg {cfg}: {e}")
+                continue
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 20
+            e0.record()
+            for _ in range(n):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / n
+            print(f"{name:10s} M={B*Ho*Wo:7d} N={co:4d} K={k*k*ci:5d} cfg {cfg}: {us:9.1f} us  {flops/us/1e6:6.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
