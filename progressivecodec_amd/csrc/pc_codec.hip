@@ -19,6 +19,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -90,11 +92,17 @@ struct pc_codec {
     double prof_flops = 0.0;
     struct ProfRec { int M, N, K, nphase, epi; double flops; };
     std::vector<ProfRec> prof_rec;
+    // slice-chain lanes: one pair of non-blocking streams per sub-batch
+    struct Lane { hipStream_t sA = nullptr, sB = nullptr; hipEvent_t eA = nullptr, eB = nullptr, eDone = nullptr; };
+    std::vector<Lane> lanes;
+    hipEvent_t eFork = nullptr;
+    std::mutex buf_mu;
     // last-call geometry for taps
     int last_B = 0, last_h16 = 0, last_w16 = 0;
 
     template <typename T> int buf(const std::string& name, size_t count, T** out)
     {
+        std::lock_guard<std::mutex> lk(buf_mu);
         DevBuf& d = bufs[name];
         const size_t need = count * sizeof(T);
         if (d.bytes < need) {
@@ -633,6 +641,8 @@ extern "C" void pc_codec_destroy(pc_codec* c)
     for (void* p : c->weight_allocs) (void)hipFree(p);
     for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (auto& L : c->lanes) { (void)hipStreamDestroy(L.sA); (void)hipStreamDestroy(L.sB); (void)hipEventDestroy(L.eA); (void)hipEventDestroy(L.eB); (void)hipEventDestroy(L.eDone); }
+    if (c->eFork) (void)hipEventDestroy(c->eFork);
     if (c->h_sym) (void)hipHostFree(c->h_sym);
     if (c->h_idx) (void)hipHostFree(c->h_idx);
     delete c;
@@ -748,6 +758,202 @@ extern "C" int pc_codec_get_string(const pc_codec* c, int slice, int b, const ui
     return PC_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- slice chain
+// The 20-step chain is serial per image but independent across images, and inside a step the mean and
+// scale stacks are independent.  Its GEMMs are small (M = B*h*w rows), so the chain is run as `n_lanes`
+// sub-batches, each on its own pair of non-blocking HIP streams (mean/prep/LRP on sA, scale (+quantile) on
+// sB, joined with events): up to 2*n_lanes kernels are resident at once and fill the MFMA pipes that one
+// such kernel leaves ~50 % idle; in the decoder each lane is driven by its own host thread, so one lane's
+// host rANS round trip overlaps the other lanes' GPU work.  Results do not depend on the split
+// (numeric contract: no cross-image arithmetic), which tests/test_gpu_codec.py checks.
+namespace {
+
+struct ChainCtx {
+    pc_codec* c;
+    int B, h, w, HW;
+    size_t M;                                   // B * HW
+    float *y, *lm, *ls, *yb, *ye, *mu, *scale, *thr, *masks;
+    int32_t *sym, *idx;
+    int mode; float q; bool enh;
+};
+
+template <typename T> inline T* img(T* p, int b0, size_t per_image) { return p ? p + (size_t)b0 * per_image : nullptr; }
+
+int ensure_lanes(pc_codec* c, int n)
+{
+    while ((int)c->lanes.size() < n) {
+        pc_codec::Lane L;
+        HIPCHK(hipStreamCreateWithFlags(&L.sA, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&L.sB, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&L.eA, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&L.eB, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&L.eDone, hipEventDisableTiming));
+        c->lanes.push_back(L);
+    }
+    if (!c->eFork) HIPCHK(hipEventCreateWithFlags(&c->eFork, hipEventDisableTiming));
+    return PC_OK;
+}
+
+int lane_count(const pc_codec* c, int B)
+{
+    static const int env = [] { const char* v = std::getenv("PC_LANES"); return v ? std::atoi(v) : 0; }();
+    int n = env > 0 ? env : 2;
+    if (c->profile) n = 1;
+    return std::max(1, std::min(n, std::min(B, 8)));
+}
+
+// mean / scale stacks (+ quantile threshold) of chain step `step` (0..9 base, 10..19 enhancement) for images [b0, b0+nb)
+int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hipStream_t sB, hipEvent_t eA, hipEvent_t eB,
+                 const std::string& tag)
+{
+    pc_codec* c = k.c;
+    const size_t pi = (size_t)k.HW;             // pixels per image
+    float* lm = img(k.lm, b0, pi * MLAT); float* ls = img(k.ls, b0, pi * MLAT);
+    float* yb = img(k.yb, b0, pi * D0); float* ye = img(k.ye, b0, pi * D0);
+    float* mu_i = k.mu + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+    float* sc_i = k.scale + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+    const bool two = sB != sA;
+    if (two) { HIPCHK(hipEventRecord(eA, sA)); HIPCHK(hipStreamWaitEvent(sB, eA, 0)); }
+    const std::string tm = "s5m" + tag, ts = "s5s" + tag;
+    if (step < NS0) {
+        const int i = step, ns = std::min(5, i);
+        PCCHK(stack5(c, sA, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
+        PCCHK(stack5(c, sB, c->cc_scale[i], {{ls, MLAT, D0}, {yb, D0, 32 * ns}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
+    } else {
+        const int i = step - NS0, s = std::min(5, i);
+        PCCHK(stack5(c, sA, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
+        PCCHK(stack5(c, sB, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
+        if (k.mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, k.thr + (size_t)i * k.B + b0, nullptr, sB));   // :819-824
+    }
+    if (two) { HIPCHK(hipEventRecord(eB, sB)); HIPCHK(hipStreamWaitEvent(sA, eB, 0)); }
+    return PC_OK;
+}
+
+// LRP stack of chain step `step` (in place on the decoded slice), images [b0, b0+nb)
+int chain_lrp(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, const std::string& tag)
+{
+    pc_codec* c = k.c;
+    const size_t pi = (size_t)k.HW;
+    float* lm = img(k.lm, b0, pi * MLAT);
+    float* yb = img(k.yb, b0, pi * D0); float* ye = img(k.ye, b0, pi * D0);
+    const std::string tm = "s5m" + tag;
+    if (step < NS0) {
+        const int i = step;
+        if (i < 5)
+            return stack5(c, sA, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 32 * (i + 1)}}, nb, k.h, k.w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, tm.c_str());
+        return stack5(c, sA, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 160}, {yb + 32 * i, D0, 32}}, nb, k.h, k.w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, tm.c_str());
+    }
+    const int i = step - NS0, s = std::min(5, i);
+    return stack5(c, sA, c->lrp_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * (s + 1)}}, nb, k.h, k.w,
+                  ye + 32 * i, D0, PC_EPI_LRP_ADD, ye + 32 * i, D0, yb + 32 * i, D0, tm.c_str());
+}
+
+int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t sB, hipEvent_t eA, hipEvent_t eB, const std::string& tag)
+{
+    pc_codec* c = k.c;
+    const size_t pi = (size_t)k.HW;
+    const int n_steps = k.enh ? 2 * NS0 : NS0;
+    for (int step = 0; step < n_steps; ++step) {
+        PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
+        const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+        if (step < NS0) {                                                                // base slices, :729-764
+            PCCHK(pc_gc_prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT, nullptr, 0, nullptr, 0,
+                                    nb, k.HW, c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, nullptr,
+                                    img(k.yb, b0, pi * D0) + 32 * step, D0, sA));
+        } else {                                                                         // enhancement slices, :775-845
+            const int i = step - NS0;
+            float* m = k.masks ? k.masks + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE : nullptr;
+            PCCHK(pc_gc_prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT,
+                                    img(k.y, b0, pi * MLAT) + 32 * i, MLAT, k.thr + (size_t)i * k.B + b0, k.mode, nb, k.HW,
+                                    c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, m,
+                                    img(k.ye, b0, pi * D0) + 32 * i, D0, sA));
+        }
+        PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
+    }
+    return PC_OK;
+}
+
+int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t sB, hipEvent_t eA, hipEvent_t eB, const std::string& tag,
+                const uint8_t* const* y_strings, const size_t* y_lens, int nt)
+{
+    pc_codec* c = k.c;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t pi = (size_t)k.HW, per = (size_t)SLICE * k.HW;
+    int32_t* h_idx = c->h_idx + (size_t)b0 * per;
+    int32_t* h_sym = c->h_sym + (size_t)b0 * per;
+    const int n_steps = k.enh ? 2 * NS0 : NS0;
+    for (int step = 0; step < n_steps; ++step) {
+        PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
+        const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+        const bool e = step >= NS0;
+        const int i = e ? step - NS0 : step;
+        PCCHK(pc_gc_prep_decode_index(k.scale + so, SLICE, e ? k.thr + (size_t)i * k.B + b0 : nullptr, e ? k.mode : 0, nb, k.HW,
+                                      c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA));
+        HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
+        HIPCHK(hipStreamSynchronize(sA));
+        PCCHK(pc_rans_decode_batch(y_strings + (size_t)step * k.B + b0, y_lens + (size_t)step * k.B + b0, nb, h_idx, per,
+                                   c->gc.cdf.data(), c->gc.n, c->gc.stride, c->gc.len.data(), c->gc.off.data(), h_sym, nt));   // :894,969
+        HIPCHK(hipMemcpyAsync(k.sym + so, h_sym, per * nb * 4, hipMemcpyHostToDevice, sA));
+        float* dst = e ? img(k.ye, b0, pi * D0) + 32 * i : img(k.yb, b0, pi * D0) + 32 * i;
+        PCCHK(pc_gc_dequantize(k.sym + so, k.mu + so, SLICE, nb, k.HW, dst, D0, sA));                                          // :896,971
+        PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
+        // the H2D copy out of h_sym is ordered before the next step's host decode by that step's hipStreamSynchronize(sA)
+    }
+    return PC_OK;
+}
+
+// run the chain over all images: fork lanes off `st`, join back
+int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* const* y_strings, const size_t* y_lens)
+{
+    pc_codec* c = k.c;
+    const int nl = lane_count(c, k.B);
+    if (nl == 1) {   // sequential on the caller's stream (also the profiling configuration)
+        static const bool two = [] { const char* v = std::getenv("PC_DUAL_STREAM"); return !v || std::atoi(v) != 0; }();
+        if (!two || c->profile) {
+            return decode ? decode_lane(k, 0, k.B, st, st, nullptr, nullptr, "", y_strings, y_lens, c->n_threads == 1 ? 1 : 0)
+                          : encode_lane(k, 0, k.B, st, st, nullptr, nullptr, "");
+        }
+    }
+    PCCHK(ensure_lanes(c, nl));
+    // pre-create every lane's workspace (no allocation inside lanes / threads)
+    for (int g = 0; g < nl; ++g) {
+        const int b0 = (int)((long)k.B * g / nl), nb = (int)((long)k.B * (g + 1) / nl) - b0;
+        const size_t m = (size_t)nb * k.HW;
+        float* dummy;
+        for (const char* base : {"s5m", "s5s"}) {
+            PCCHK(c->buf(std::string(base) + std::to_string(g) + "_t0", m * 224, &dummy));
+            PCCHK(c->buf(std::string(base) + std::to_string(g) + "_t1", m * 176, &dummy));
+        }
+    }
+    HIPCHK(hipEventRecord(c->eFork, st));
+    std::vector<int> rcs(nl, PC_OK);
+    std::vector<std::thread> threads;
+    for (int g = 0; g < nl; ++g) {
+        const int b0 = (int)((long)k.B * g / nl), nb = (int)((long)k.B * (g + 1) / nl) - b0;
+        pc_codec::Lane& L = c->lanes[g];
+        HIPCHK(hipStreamWaitEvent(L.sA, c->eFork, 0));
+        const std::string tag = std::to_string(g);
+        if (decode) {
+            threads.emplace_back([&, g, b0, nb, tag] {
+                pc_codec::Lane& LL = c->lanes[g];
+                rcs[g] = decode_lane(k, b0, nb, LL.sA, LL.sB, LL.eA, LL.eB, tag, y_strings, y_lens, c->n_threads == 1 ? 1 : 0);
+            });
+        } else {
+            rcs[g] = encode_lane(k, b0, nb, L.sA, L.sB, L.eA, L.eB, tag);
+        }
+    }
+    for (auto& t : threads) t.join();
+    for (int g = 0; g < nl; ++g) {
+        pc_codec::Lane& L = c->lanes[g];
+        HIPCHK(hipEventRecord(L.eDone, L.sA));
+        HIPCHK(hipStreamWaitEvent(st, L.eDone, 0));
+    }
+    for (int g = 0; g < nl; ++g) if (rcs[g] != PC_OK) return rcs[g];
+    return PC_OK;
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------------------------- compress
 extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
                                  float* masks_out, void* stream)
@@ -764,64 +970,37 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     const int n_slices = quality <= 0 ? NS0 : 2 * NS0;
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
 
-    float *y, *z, *z_hat, *lm, *ls, *yb, *ye, *mu, *scale, *thr;
-    int32_t *z_sym, *sym, *idx;
-    PCCHK(c->buf("y", M * MLAT, &y));
+    ChainCtx k;
+    std::memset(&k, 0, sizeof(k));
+    float *z, *z_hat;
+    int32_t* z_sym;
+    PCCHK(c->buf("y", M * MLAT, &k.y));
     PCCHK(c->buf("z", (size_t)B * ZHW * NCH, &z));
     PCCHK(c->buf("z_hat", (size_t)B * ZHW * NCH, &z_hat));
     PCCHK(c->buf("z_sym", (size_t)B * ZHW * NCH, &z_sym));
-    PCCHK(c->buf("latent_means", M * MLAT, &lm));
-    PCCHK(c->buf("latent_scales", M * MLAT, &ls));
-    PCCHK(c->buf("yhat_base", M * D0, &yb));
-    PCCHK(c->buf("yhat_enh", M * D0, &ye));
-    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &mu));            // per-slice mu / scale kept for taps
-    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &scale));
-    PCCHK(c->buf("thr", (size_t)B * NS0, &thr));
-    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &sym));
-    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &idx));
+    PCCHK(c->buf("latent_means", M * MLAT, &k.lm));
+    PCCHK(c->buf("latent_scales", M * MLAT, &k.ls));
+    PCCHK(c->buf("yhat_base", M * D0, &k.yb));
+    PCCHK(c->buf("yhat_enh", M * D0, &k.ye));
+    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &k.mu));            // per-slice mu / scale kept for taps
+    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &k.scale));
+    PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
+    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
+    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
+    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M; k.masks = masks_out; k.enh = n_slices > NS0;
+    k.mode = k.enh ? mask_mode_for(mask_pol, quality, &k.q) : 0;
 
-    PCCHK(g_a(c, st, x, B, H, W, y));                                                    // :692
-    PCCHK(h_a(c, st, y, B, h, w, z));                                                    // :700
+    PCCHK(g_a(c, st, x, B, H, W, k.y));                                                  // :692
+    PCCHK(h_a(c, st, k.y, B, h, w, z));                                                  // :700
     PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :702-704
-    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, lm, ls));                              // :705-715
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :705-715
+    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :729-845
 
-    for (int i = 0; i < NS0; ++i) {                                                      // base slices, :729-764
-        const int ns = std::min(5, i);
-        float* mu_i = mu + (size_t)i * M * SLICE;
-        float* sc_i = scale + (size_t)i * M * SLICE;
-        PCCHK(stack5(c, st, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
-        PCCHK(stack5(c, st, c->cc_scale[i], {{ls, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
-        PCCHK(pc_gc_prep_encode(sc_i, SLICE, mu_i, SLICE, y + 32 * i, MLAT, nullptr, 0, nullptr, 0, B, HW,
-                                c->scale_table, c->n_table, c->scale_bound,
-                                sym + (size_t)i * M * SLICE, idx + (size_t)i * M * SLICE, nullptr, yb + 32 * i, D0, st));
-        if (i < 5)
-            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 32 * (i + 1)}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
-        else
-            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 160}, {yb + 32 * i, D0, 32}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
-    }
-    if (n_slices > NS0) {
-        float q = 0.0f;
-        const int mode = mask_mode_for(mask_pol, quality, &q);
-        for (int i = 0; i < NS0; ++i) {                                                  // enhancement slices, :775-845
-            const int s = std::min(5, i);
-            float* mu_i = mu + (size_t)(NS0 + i) * M * SLICE;
-            float* sc_i = scale + (size_t)(NS0 + i) * M * SLICE;
-            PCCHK(stack5(c, st, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
-            PCCHK(stack5(c, st, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
-            if (mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, B, HW, SLICE, q, thr + (size_t)i * B, nullptr, st));   // :819-824
-            PCCHK(pc_gc_prep_encode(sc_i, SLICE, mu_i, SLICE, y + 32 * (NS0 + i), MLAT, y + 32 * i, MLAT, thr + (size_t)i * B, mode, B, HW,
-                                    c->scale_table, c->n_table, c->scale_bound,
-                                    sym + (size_t)(NS0 + i) * M * SLICE, idx + (size_t)(NS0 + i) * M * SLICE,
-                                    masks_out ? masks_out + (size_t)i * M * SLICE : nullptr, ye + 32 * i, D0, st));
-            PCCHK(stack5(c, st, c->lrp_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * (s + 1)}}, B, h, w,
-                         ye + 32 * i, D0, PC_EPI_LRP_ADD, ye + 32 * i, D0, yb + 32 * i, D0, "s5m"));
-        }
-    }
     // ---- symbols/indexes to the host, rANS on the thread pool  (entropy_models.py:226-235)
     const size_t n_y = (size_t)n_slices * M * SLICE, n_z = (size_t)B * ZHW * NCH;
     PCCHK(ensure_host_staging(c, n_y + n_z));
-    HIPCHK(hipMemcpyAsync(c->h_sym, sym, n_y * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_idx, idx, n_y * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_sym, k.sym, n_y * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_y * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_sym + n_y, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (size_t e = 0; e < n_z; ++e) c->h_idx[n_y + e] = (int32_t)((e / ZHW) % NCH);     // EntropyBottleneck._build_indexes :492-502
@@ -865,19 +1044,23 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
     const size_t M = (size_t)B * HW;
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
 
-    float *z_hat, *lm, *ls, *yb, *ye, *mu, *scale, *thr;
-    int32_t *z_sym, *sym, *idx;
+    ChainCtx k;
+    std::memset(&k, 0, sizeof(k));
+    float* z_hat;
+    int32_t* z_sym;
     PCCHK(c->buf("z_hat", (size_t)B * ZHW * NCH, &z_hat));
     PCCHK(c->buf("z_sym", (size_t)B * ZHW * NCH, &z_sym));
-    PCCHK(c->buf("latent_means", M * MLAT, &lm));
-    PCCHK(c->buf("latent_scales", M * MLAT, &ls));
-    PCCHK(c->buf("yhat_base", M * D0, &yb));
-    PCCHK(c->buf("yhat_enh", M * D0, &ye));
-    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &mu));
-    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &scale));
-    PCCHK(c->buf("thr", (size_t)B * NS0, &thr));
-    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &sym));
-    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &idx));
+    PCCHK(c->buf("latent_means", M * MLAT, &k.lm));
+    PCCHK(c->buf("latent_scales", M * MLAT, &k.ls));
+    PCCHK(c->buf("yhat_base", M * D0, &k.yb));
+    PCCHK(c->buf("yhat_enh", M * D0, &k.ye));
+    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &k.mu));
+    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &k.scale));
+    PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
+    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
+    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
+    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M; k.enh = quality != 0;
+    k.mode = k.enh ? mask_mode_for(mask_pol, quality, &k.q) : 0;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
     PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
     const int nt = c->n_threads == 1 ? 1 : 0;
@@ -888,53 +1071,10 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
                                c->eb.off.data(), c->h_sym, nt));
     HIPCHK(hipMemcpyAsync(z_sym, c->h_sym, per_z * B * 4, hipMemcpyHostToDevice, st));
     PCCHK(pc_eb_dequant_launch(z_sym, B, ZHW, NCH, c->medians, z_hat, st));
-    HIPCHK(hipStreamSynchronize(st));   // h_sym is reused below
-    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, lm, ls));                              // :856-867
-
-    auto decode_slice = [&](int slice, const float* sc_i, const float* mu_i, const float* thr_i, int mode, float* yhat_dst) -> int {
-        int32_t* idx_i = idx + (size_t)slice * M * SLICE;
-        int32_t* sym_i = sym + (size_t)slice * M * SLICE;
-        PCCHK(pc_gc_prep_decode_index(sc_i, SLICE, thr_i, mode, B, HW, c->scale_table, c->n_table, c->scale_bound, idx_i, nullptr, st));
-        HIPCHK(hipMemcpyAsync(c->h_idx, idx_i, per * B * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        PCCHK(pc_rans_decode_batch(y_strings + (size_t)slice * B, y_lens + (size_t)slice * B, B, c->h_idx, per, c->gc.cdf.data(), c->gc.n,
-                                   c->gc.stride, c->gc.len.data(), c->gc.off.data(), c->h_sym, nt));
-        HIPCHK(hipMemcpyAsync(sym_i, c->h_sym, per * B * 4, hipMemcpyHostToDevice, st));
-        PCCHK(pc_gc_dequantize(sym_i, mu_i, SLICE, B, HW, yhat_dst, D0, st));
-        HIPCHK(hipStreamSynchronize(st));   // staging buffer reuse
-        return PC_OK;
-    };
-
-    for (int i = 0; i < NS0; ++i) {                                                      // :874-904
-        const int ns = std::min(5, i);
-        float* mu_i = mu + (size_t)i * M * SLICE;
-        float* sc_i = scale + (size_t)i * M * SLICE;
-        PCCHK(stack5(c, st, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
-        PCCHK(stack5(c, st, c->cc_scale[i], {{ls, MLAT, D0}, {yb, D0, 32 * ns}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
-        PCCHK(decode_slice(i, sc_i, mu_i, nullptr, 0, yb + 32 * i));
-        if (i < 5)
-            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 32 * (i + 1)}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
-        else
-            PCCHK(stack5(c, st, c->lrp[i], {{lm, MLAT, D0}, {yb, D0, 160}, {yb + 32 * i, D0, 32}}, B, h, w, yb + 32 * i, D0, PC_EPI_LRP, yb + 32 * i, D0, nullptr, 0, "s5m"));
-    }
-    if (quality == 0) {                                                                  // :907-916
-        PCCHK(g_s(c, st, c->gs[0], yb, B, h, w, x_hat));
-        return PC_OK;
-    }
-    float q = 0.0f;
-    const int mode = mask_mode_for(mask_pol, quality, &q);
-    for (int i = 0; i < NS0; ++i) {                                                      // :921-983
-        const int s = std::min(5, i);
-        float* mu_i = mu + (size_t)(NS0 + i) * M * SLICE;
-        float* sc_i = scale + (size_t)(NS0 + i) * M * SLICE;
-        PCCHK(stack5(c, st, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5m"));
-        PCCHK(stack5(c, st, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, B, h, w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, "s5s"));
-        if (mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, B, HW, SLICE, q, thr + (size_t)i * B, nullptr, st));
-        PCCHK(decode_slice(NS0 + i, sc_i, mu_i, thr + (size_t)i * B, mode, ye + 32 * i));
-        PCCHK(stack5(c, st, c->lrp_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * (s + 1)}}, B, h, w,
-                     ye + 32 * i, D0, PC_EPI_LRP_ADD, ye + 32 * i, D0, yb + 32 * i, D0, "s5m"));
-    }
-    PCCHK(g_s(c, st, c->gs[1], ye, B, h, w, x_hat));                                     // :986-990
+    HIPCHK(hipStreamSynchronize(st));   // h_sym is reused by the lanes
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :856-867
+    PCCHK(run_chain(k, st, true, y_strings, y_lens));                                    // :874-983
+    PCCHK(g_s(c, st, c->gs[k.enh ? 1 : 0], k.enh ? k.ye : k.yb, B, h, w, x_hat));       // :907-916 / :986-990
     return PC_OK;
 }
 

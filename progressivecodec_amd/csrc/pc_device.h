@@ -61,6 +61,7 @@ struct pc_conv_params {
     const float* aux0; int ld0;
     const float* aux1; int ld1;
     int tile_cfg;
+    int dbg;                                 // tuning ablations only (PC_CONV_DBG): 1 = skip MFMA, 2 = skip loader work
 };
 
 int pc_conv_launch(const pc_conv_params& p, hipStream_t stream);

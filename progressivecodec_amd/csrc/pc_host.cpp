@@ -190,7 +190,7 @@ namespace pc {
 
 struct ThreadPool::Impl {
     std::vector<std::thread> workers;
-    std::mutex mu;
+    std::mutex mu, call_mu;   // call_mu serialises concurrent parallel_for callers (decoder lanes)
     std::condition_variable cv_work, cv_done;
     const std::function<void(size_t)>* fn = nullptr;
     size_t n_items = 0;
@@ -243,6 +243,7 @@ void ThreadPool::parallel_for(size_t n, const std::function<void(size_t)>& fn)
     Impl& s = *impl_;
     if (n == 0) return;
     if (s.workers.empty() || n == 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    std::lock_guard<std::mutex> call_lk(s.call_mu);
     {
         std::lock_guard<std::mutex> lk(s.mu);
         s.fn = &fn; s.n_items = n; s.next = 0; s.active = s.workers.size(); ++s.generation;

@@ -27,10 +27,13 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
 
 
 def main():
-    cfgs = [int(a) for a in sys.argv[1:]] or [0]
+    names = [a for a in sys.argv[1:] if not a.isdigit()]
+    cfgs = [int(a) for a in sys.argv[1:] if a.isdigit()] or [0]
     L = lib()
     rng = np.random.default_rng(0)
     for name, B, H, W, ci, co, k, s in SHAPES:
+        if names and name not in names:
+            continue
         x = torch.from_numpy(rng.standard_normal((B, H, W, ci)).astype(np.float32)).cuda()
         w = torch.from_numpy((rng.standard_normal((k * k, ci, co)) * 0.05).astype(np.float32)).cuda()
         b = torch.zeros(co, device="cuda")
