@@ -43,7 +43,7 @@ const int CC_W[5] = {224, 176, 128, 64, 32};
 
 struct HostTensor { std::vector<uint8_t> data; std::vector<int64_t> shape; int dtype; };
 
-struct ConvW { float* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, k = 0, kind = 0; };
+struct ConvW { float* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, k = 0, kind = 0, layout = 0; };
 struct GdnW { float* beta = nullptr; float* gamma_t = nullptr; int C = 0; };
 struct RuW { ConvW c0, c2, c4; };
 struct WamW { RuW a[3], b[3]; ConvW qkv, proj, out; float* bias = nullptr; int C = 0, ws = 0, shift = 0; };
@@ -130,7 +130,7 @@ int launch_conv(const pc_conv_params& q, hipStream_t st)
     }
     long taps = 0;
     for (int ph = 0; ph < q.nphase; ++ph) taps += q.ntap[ph];
-    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin;
+    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin * (q.ngroup == 2 ? 2.0 : 1.0);
     c->prof_flops += fl;
     c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl});
     HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
@@ -170,7 +170,7 @@ int load_conv(pc_codec* c, const std::string& p, int Cin, int Cout, int k, int k
     PCCHK(upload(c, packed, &out->w));
     std::vector<float> bias(reinterpret_cast<const float*>(b->data.data()), reinterpret_cast<const float*>(b->data.data()) + Cout);
     PCCHK(upload(c, bias, &out->b));
-    out->Cin = Cin; out->Cout = Cout; out->k = k; out->kind = kind;
+    out->Cin = Cin; out->Cout = Cout; out->k = k; out->kind = kind; out->layout = pc_conv_weight_layout(kind, Cin, Cout, k);
     return PC_OK;
 }
 
@@ -184,7 +184,7 @@ int load_linear(pc_codec* c, const std::string& p, int Cin, int Cout, ConvW* out
     PCCHK(upload(c, packed, &out->w));
     std::vector<float> bias(reinterpret_cast<const float*>(b->data.data()), reinterpret_cast<const float*>(b->data.data()) + Cout);
     PCCHK(upload(c, bias, &out->b));
-    out->Cin = Cin; out->Cout = Cout; out->k = 1; out->kind = 0;
+    out->Cin = Cin; out->Cout = Cout; out->k = 1; out->kind = 0; out->layout = pc_conv_weight_layout(0, Cin, Cout, 1);
     return PC_OK;
 }
 
@@ -293,9 +293,11 @@ void fill_deconv_taps(pc_conv_params& q)   // ConvTranspose2d(5, s2, p2, op1) as
 }
 
 // generic conv over NHWC segments -> NHWC output slice (channel offset folded into `out`, pixel stride ldo)
+struct Group1 { const ConvW* w; const float* seg0; float* out; };   // second GEMM of a grouped launch
+
 int conv(hipStream_t st, const ConvW& w, std::initializer_list<Seg> segs, int B, int H, int W, int stride,
          float* out, int ldo, int epi, const float* aux0 = nullptr, int ld0 = 0, const float* aux1 = nullptr, int ld1 = 0,
-         bool pixel_shuffle = false)
+         bool pixel_shuffle = false, const Group1* g1 = nullptr)
 {
     pc_conv_params q;
     std::memset(&q, 0, sizeof(q));
@@ -307,7 +309,7 @@ int conv(hipStream_t st, const ConvW& w, std::initializer_list<Seg> segs, int B,
     }
     if (cin != w.Cin) return PC_ERR_ARG;
     q.Cin = cin; q.B = B; q.H = H; q.W = W;
-    q.w = w.w; q.bias = w.b; q.Cout = w.Cout;
+    q.w = w.w; q.wlayout = w.layout; q.bias = w.b; q.Cout = w.Cout;
     q.epi = epi; q.aux0 = aux0; q.ld0 = ld0; q.aux1 = aux1; q.ld1 = ld1;
     q.out = out;
     if (w.kind == 0) {
@@ -323,6 +325,10 @@ int conv(hipStream_t st, const ConvW& w, std::initializer_list<Seg> segs, int B,
     q.pixel_shuffle = pixel_shuffle ? 1 : 0;
     if (pixel_shuffle) { q.outH *= 2; q.outW *= 2; }
     q.out_sc = 1; q.out_sx = ldo; q.out_sy = (int64_t)q.outW * ldo; q.out_sb = (int64_t)q.outH * q.outW * ldo;
+    if (g1) {
+        if (g1->w->Cin != w.Cin || g1->w->Cout != w.Cout || g1->w->k != w.k || g1->w->layout != 1 || w.layout != 1) return PC_ERR_ARG;
+        q.ngroup = 2; q.g1_seg0 = g1->seg0; q.g1_w = g1->w->w; q.g1_bias = g1->w->b; q.g1_out = g1->out;
+    }
     return launch_conv(q, st);
 }
 
@@ -391,6 +397,30 @@ int stack5(pc_codec* c, hipStream_t st, const Stack5W& s, std::initializer_list<
     PCCHK(conv(st, s.c[2], {{t1, 176, 176}}, B, h, w, 1, t0, 128, PC_EPI_GELU));
     PCCHK(conv(st, s.c[3], {{t0, 128, 128}}, B, h, w, 1, t1, 64, PC_EPI_GELU));
     PCCHK(conv(st, s.c[4], {{t1, 64, 64}}, B, h, w, 1, out, ldo, epi, aux0, ld0, aux1, ld1));
+    return PC_OK;
+}
+
+// cc_mean || cc_scale of one chain step as five grouped launches (identical shapes; the supports differ only in
+// their first segment: latent_means vs latent_scales)
+int stack5_pair(pc_codec* c, hipStream_t st, const Stack5W& sm, const Stack5W& ss, std::initializer_list<Seg> segs_mean,
+                const float* seg0_scale, int B, int h, int w, float* out_mean, float* out_scale, const char* tagm, const char* tags)
+{
+    const size_t M = (size_t)B * h * w;
+    float *m0, *m1, *s0, *s1;
+    PCCHK(c->buf(std::string(tagm) + "_t0", M * 224, &m0));
+    PCCHK(c->buf(std::string(tagm) + "_t1", M * 176, &m1));
+    PCCHK(c->buf(std::string(tags) + "_t0", M * 224, &s0));
+    PCCHK(c->buf(std::string(tags) + "_t1", M * 176, &s1));
+    Group1 g{&ss.c[0], seg0_scale, s0};
+    PCCHK(conv(st, sm.c[0], segs_mean, B, h, w, 1, m0, 224, PC_EPI_GELU, nullptr, 0, nullptr, 0, false, &g));
+    g = Group1{&ss.c[1], s0, s1};
+    PCCHK(conv(st, sm.c[1], {{m0, 224, 224}}, B, h, w, 1, m1, 176, PC_EPI_GELU, nullptr, 0, nullptr, 0, false, &g));
+    g = Group1{&ss.c[2], s1, s0};
+    PCCHK(conv(st, sm.c[2], {{m1, 176, 176}}, B, h, w, 1, m0, 128, PC_EPI_GELU, nullptr, 0, nullptr, 0, false, &g));
+    g = Group1{&ss.c[3], s0, s1};
+    PCCHK(conv(st, sm.c[3], {{m0, 128, 128}}, B, h, w, 1, m1, 64, PC_EPI_GELU, nullptr, 0, nullptr, 0, false, &g));
+    g = Group1{&ss.c[4], s1, out_scale};
+    PCCHK(conv(st, sm.c[4], {{m1, 64, 64}}, B, h, w, 1, out_mean, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, false, &g));
     return PC_OK;
 }
 
@@ -526,14 +556,29 @@ int hyper(pc_codec* c, hipStream_t st, const float* z_hat, int B, int zh, int zw
 extern "C" int pc_pack_conv_weight(const float* w, int kind, int Cout, int Cin, int k, float* out)
 {
     if (!w || !out || Cout <= 0 || Cin <= 0 || k <= 0) return PC_ERR_ARG;
-    // -> [ky*k+kx][Cin][Cout]
-    for (int ky = 0; ky < k; ++ky)
-        for (int kx = 0; kx < k; ++kx)
-            for (int ci = 0; ci < Cin; ++ci) {
-                float* dst = out + (((size_t)(ky * k + kx) * Cin) + ci) * Cout;
-                if (kind == 0) for (int co = 0; co < Cout; ++co) dst[co] = w[(((size_t)co * Cin + ci) * k + ky) * k + kx];
-                else for (int co = 0; co < Cout; ++co) dst[co] = w[(((size_t)ci * Cout + co) * k + ky) * k + kx];
-            }
+    auto src = [&](int co, int ci, int ky, int kx) -> float {
+        return kind == 0 ? w[(((size_t)co * Cin + ci) * k + ky) * k + kx] : w[(((size_t)ci * Cout + co) * k + ky) * k + kx];
+    };
+    if (pc_conv_weight_layout(kind, Cin, Cout, k) == 0) {
+        // layout 0: [ky*k+kx][Cin][Cout]
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+                for (int ci = 0; ci < Cin; ++ci) {
+                    float* dst = out + (((size_t)(ky * k + kx) * Cin) + ci) * Cout;
+                    for (int co = 0; co < Cout; ++co) dst[co] = src(co, ci, ky, kx);
+                }
+    } else {
+        // layout 1: [ky*k+kx][Cout][Cin], channels permuted inside aligned groups of 8 to (0,2,4,6,1,3,5,7)
+        for (int ky = 0; ky < k; ++ky)
+            for (int kx = 0; kx < k; ++kx)
+                for (int co = 0; co < Cout; ++co) {
+                    float* dst = out + (((size_t)(ky * k + kx) * Cout) + co) * Cin;
+                    for (int ci = 0; ci < Cin; ++ci) {
+                        const int r = ci & 7;
+                        dst[(ci & ~7) + (r >> 1) + 4 * (r & 1)] = src(co, ci, ky, kx);
+                    }
+                }
+    }
     return PC_OK;
 }
 
@@ -547,6 +592,7 @@ extern "C" int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, cons
     q.B = B; q.H = H; q.W = W;
     if (Cin % 16) { q.smallc = 1; q.in_sc = 1; q.in_sx = Cin; q.in_sy = (int64_t)W * Cin; q.in_sb = (int64_t)H * W * Cin; if (kind != 0) return PC_ERR_ARG; }
     q.w = w_packed; q.bias = bias; q.Cout = Cout; q.epi = act ? PC_EPI_GELU : PC_EPI_NONE; q.tile_cfg = tile_cfg;
+    q.wlayout = pc_conv_weight_layout(kind, Cin, Cout, k);
     if (kind == 0) {
         fill_conv_taps(q, k, stride);
         q.Ho = (H + 2 * (k / 2) - k) / stride + 1; q.Wo = (W + 2 * (k / 2) - k) / stride + 1; q.outH = q.Ho; q.outW = q.Wo;
@@ -812,9 +858,22 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
     float* yb = img(k.yb, b0, pi * D0); float* ye = img(k.ye, b0, pi * D0);
     float* mu_i = k.mu + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
     float* sc_i = k.scale + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+    static const bool grouped = [] { const char* v = std::getenv("PC_GROUPED"); return !v || std::atoi(v) != 0; }();
+    const std::string tm = "s5m" + tag, ts = "s5s" + tag;
+    if (grouped) {   // one grouped launch per layer: mean (z = 0) and scale (z = 1)
+        if (step < NS0) {
+            const int i = step, ns = std::min(5, i);
+            PCCHK(stack5_pair(c, sA, c->cc_mean[i], c->cc_scale[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, ls, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
+        } else {
+            const int i = step - NS0, s = std::min(5, i);
+            PCCHK(stack5_pair(c, sA, c->cc_mean_p[i], c->cc_scale_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}},
+                              ls + D0, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
+            if (k.mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, k.thr + (size_t)i * k.B + b0, nullptr, sA));
+        }
+        return PC_OK;
+    }
     const bool two = sB != sA;
     if (two) { HIPCHK(hipEventRecord(eA, sA)); HIPCHK(hipStreamWaitEvent(sB, eA, 0)); }
-    const std::string tm = "s5m" + tag, ts = "s5s" + tag;
     if (step < NS0) {
         const int i = step, ns = std::min(5, i);
         PCCHK(stack5(c, sA, c->cc_mean[i], {{lm, MLAT, D0}, {yb, D0, 32 * ns}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));

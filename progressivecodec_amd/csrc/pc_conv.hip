@@ -254,247 +254,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 
 
 // ------------------------------------------------------------------------------------------
-// Main kernel (all layers with Cin % 16 == 0).  Differences from the element-gather kernel above:
-//  * K-chunk BK = 16 or 32 channels of ONE tap and ONE segment (wave-uniform iterator: tap,
-//    segment, channel live in SGPRs, parameters come through scalar loads); a segment tail shorter
-//    than BK is zero-filled (zeros leave the fmaf chain unchanged);
-//  * two chunks in flight in registers (prefetch distance 2) on top of the LDS double buffer: a
-//    global-load round trip (~1.1 us measured per chunk on the M = 8192 slice-chain GEMMs, which
-//    have <= 2 blocks per CU) is then covered by two MFMA phases instead of one;
-//  * register budget kept low (<= 128 VGPRs) because occupancy is what hides the per-chunk barrier.
-// The fmaf chain per output element is unchanged: chunks, and k inside a chunk, ascend.
+// Wave-specialised kernel with LDS-DMA loaders (weight layout 1).  Ablations of the kernel above
+// (tools/conv_tune.py, PC_CONV_DBG): loader-only 111 us + MFMA-only 165 us ~= full 246 us on the
+// 8192x224x4608 slice-chain GEMM -- loader instructions and f32 MFMAs do not overlap on a SIMD, so
+// every loader instruction costs matrix time.  Here the loader waves issue only
+// `global_load_lds_dwordx4` (16 B per lane straight into LDS, no VGPR staging, no ds_write) plus a
+// few address ops; the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE
+// address (LDS-DMA writes lane-linearly), read back conflict-free with ds_read_b128; weights are
+// pre-packed [tap][Cout][Cin] with k permuted inside aligned groups of 8 to (0,2,4,6,1,3,5,7) so a B
+// lane fetches its four next k in ONE 16-byte read.  Per 4 MFMAs an MFMA wave issues 3 ds_read_b128
+// and 4 v_cndmask.  Same fmaf chains (k ascending) as every other variant.
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
-__global__ __launch_bounds__(256) void conv_igemm2_kernel(const pc_conv_params p)
+__device__ __attribute__((aligned(64))) float pc_zero_page[16];
+
+template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
+
+template <int BK>
+__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_params p)
 {
-    constexpr int TM = BM / WAVES_M / 32, TN = BN / WAVES_N / 32;
-    constexpr int LDA = BM + 1, LDB = BN + 4;
-    constexpr int KQ = BK / 4;                        // 16-byte k-quads per A row
-    constexpr int ROWS_PER_PASS = 256 / KQ;
-    constexpr int AI = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;   // A float4 per thread per chunk
-    constexpr int BQ = BN / 4;                        // float4 per B row
-    constexpr int BROWS_PER_PASS = 256 / BQ;
-    constexpr int BI = (BK + BROWS_PER_PASS - 1) / BROWS_PER_PASS;
-    static_assert(WAVES_M * WAVES_N == 4, "4 waves per block");
-    __shared__ float smem[2 * BK * (LDA + LDB)];
-    float* As = smem;
-    float* Bs = smem + 2 * BK * LDA;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int phase = blockIdx.z;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int T = p.ntap[phase];
-    const int HoWo = p.Ho * p.Wo;
-
-    int chunks_per_tap = 0;
-    for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
-    const int nchunks = T * chunks_per_tap;
-
-    // ---- A: fixed rows, k-quad column kq
-    const int kq = tid % KQ;
-    const int arow0 = tid / KQ;
-    int a_iy0[AI], a_ix0[AI];
-    int64_t a_boff[AI];
-    bool a_ok[AI];
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-        const int row = arow0 + i * ROWS_PER_PASS;
-        const int m = m0 + row;
-        a_ok[i] = (row < BM) && (m < p.M);
-        const int mm = a_ok[i] ? m : 0;
-        const int b = mm / HoWo, r = mm - b * HoWo;
-        const int oy = r / p.Wo, ox = r - oy * p.Wo;
-        a_iy0[i] = oy * p.stride;
-        a_ix0[i] = ox * p.stride;
-        a_boff[i] = (int64_t)b * p.H * p.W;
-    }
-    // ---- B: rows bk0 + i * BROWS_PER_PASS, columns b_n
-    const int b_n = (tid % BQ) * 4;
-    const int bk0 = tid / BQ;
-    const bool b_nok = n0 + b_n < p.Cout;
-    const bool b_full = n0 + b_n + 3 < p.Cout;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    // wave-uniform chunk iterator
-    int it_t = 0, it_s = 0, it_c = 0, it_cg = 0, it_sbase = 0;
-
-    auto load_chunk = [&](float4 (&ra)[AI], float4 (&rb)[BI]) {
-        const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
-        const int nch = p.seg[it_s].nch;
-        const float* sp = p.seg[it_s].ptr + it_c + 4 * kq;
-        const int sld = p.seg[it_s].ld;
-        const bool kq_ok = it_c + 4 * kq < nch;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (kq_ok && a_ok[i] && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W)
-                v = *reinterpret_cast<const float4*>(sp + (a_boff[i] + (int64_t)iy * p.W + ix) * sld);
-            if (p.square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
-            ra[i] = v;
-        }
-        const float* wrow = p.w + ((int64_t)p.wtap[phase][it_t] * p.Cin + it_cg) * p.Cout + n0 + b_n;
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int k = bk0 + i * BROWS_PER_PASS;
-            float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (k < BK && it_c + k < nch && b_nok) {
-                const float* wp = wrow + (int64_t)k * p.Cout;
-                if (b_full) w = *reinterpret_cast<const float4*>(wp);
-                else { w.x = wp[0]; if (n0 + b_n + 1 < p.Cout) w.y = wp[1]; if (n0 + b_n + 2 < p.Cout) w.z = wp[2]; }
-            }
-            rb[i] = w;
-        }
-        it_c += BK; it_cg += BK;
-        if (it_c >= nch) {
-            it_sbase += nch; it_c = 0; it_cg = it_sbase; ++it_s;
-            if (it_s >= p.nseg) { it_s = 0; it_sbase = 0; it_cg = 0; ++it_t; }
-        }
-    };
-
-    auto store_chunk = [&](int buf, const float4 (&ra)[AI], const float4 (&rb)[BI]) {
-        float* a = As + buf * BK * LDA;
-        float* b = Bs + buf * BK * LDB;
-#pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int row = arow0 + i * ROWS_PER_PASS;
-            if (row < BM) {
-                a[(kq * 4 + 0) * LDA + row] = ra[i].x;
-                a[(kq * 4 + 1) * LDA + row] = ra[i].y;
-                a[(kq * 4 + 2) * LDA + row] = ra[i].z;
-                a[(kq * 4 + 3) * LDA + row] = ra[i].w;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < BI; ++i) {
-            const int k = bk0 + i * BROWS_PER_PASS;
-            if (k < BK) *reinterpret_cast<float4*>(b + k * LDB + b_n) = rb[i];
-        }
-    };
-
-    const int half = lane >> 5, l31 = lane & 31;
-    auto compute = [&](int buf) {
-        // operands of G k-steps are read into registers one group ahead of the MFMAs that consume them, so the
-        // LDS latency of group g+1 hides behind the 64-cycle MFMAs of group g
-        constexpr int G = 8, NG = BK / (2 * G);
-        const float* a = As + buf * BK * LDA + wm * (TM * 32) + l31 + half * LDA;
-        const float* b = Bs + buf * BK * LDB + wn * (TN * 32) + l31 + half * LDB;
-        float av[2][G][TM], bv[2][G][TN];
-        auto rd = [&](int g, int slot) {
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const int kk = 2 * (g * G + s);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[slot][s][i] = a[kk * LDA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[slot][s][j] = b[kk * LDB + j * 32];
-            }
-        };
-        rd(0, 0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the next group's LDS reads ahead of this group's MFMAs
-#pragma unroll
-            for (int s = 0; s < G; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][s][i], bv[g & 1][s][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    float4 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
-    load_chunk(ra0, rb0);
-    if (nchunks > 1) load_chunk(ra1, rb1);
-    store_chunk(0, ra0, rb0);
-    __syncthreads();
-    for (int c = 0;;) {
-        if (c + 2 < nchunks) load_chunk(ra0, rb0);
-        compute(0);
-        if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
-        __syncthreads();
-        if (++c >= nchunks) break;
-        if (c + 2 < nchunks) load_chunk(ra1, rb1);
-        compute(1);
-        if (c + 1 < nchunks) store_chunk(0, ra0, rb0);
-        __syncthreads();
-        if (++c >= nchunks) break;
-    }
-
-    // ---- epilogue
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = m0 + wm * (TM * 32) + i * 32 + row;
-            if (m >= p.M) continue;
-            const int b = m / HoWo, rr = m - b * HoWo;
-            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-            int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (n >= p.Cout) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v = v + p.bias[n];
-                int nn = n, YY = Y, XX = X;
-                if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
-                const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
-                v = epilogue_value(p, v, pix, nn);
-                p.out[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
-            }
-        }
-    }
-}
-
-template <int BM, int BN, int WAVES_M, int WAVES_N, int BK>
-hipError_t launch_cfg2(const pc_conv_params& p, hipStream_t stream)
-{
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.nphase);
-    hipLaunchKernelGGL((conv_igemm2_kernel<BM, BN, WAVES_M, WAVES_N, BK>), grid, dim3(256), 0, stream, p);
-    return hipGetLastError();
-}
-
-// ------------------------------------------------------------------------------------------
-// Wave-specialised kernel: 512 threads = 4 MFMA waves + 4 loader waves (one of each per SIMD).
-// PMC profile of the kernels above (profiles/r01_c_pmc_*.txt): per K-chunk a wave spends ~1000 cycles
-// in its 16 dependent MFMAs and ~2500 in ~225 VALU/SALU/LDS/VMEM instructions and their waits, all
-// in phase with its SIMD partner, so the matrix pipe idles ~55 % of the time.  Here the MFMA waves
-// only read operands from LDS and issue MFMAs; the loader waves do the im2col address arithmetic,
-// global loads (prefetch distance 2, registers) and LDS stores for the next chunk on the VALU/VMEM/LDS
-// pipes, which run beside the matrix pipe.  One block-wide barrier per chunk hands stage (c+1)%2 to the
-// MFMA waves.  Same fmaf chains as every other variant.
-// ------------------------------------------------------------------------------------------
-template <int TM, int TN, int BK>
-__global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const pc_conv_params p)
-{
-    constexpr int WAVES_M = 2, WAVES_N = 2;
-    constexpr int BM = 32 * TM * WAVES_M, BN = 32 * TN * WAVES_N;
-    constexpr int LDA = BM + 1, LDB = BN + 4;
-    constexpr int KQ = BK / 4;
-    constexpr int ROWS_PER_PASS = 256 / KQ;
-    constexpr int AI = (BM + ROWS_PER_PASS - 1) / ROWS_PER_PASS;
-    constexpr int BQ = BN / 4;
-    constexpr int BROWS_PER_PASS = 256 / BQ;
-    constexpr int BI = (BK + BROWS_PER_PASS - 1) / BROWS_PER_PASS;
-    __shared__ float smem[2 * BK * (LDA + LDB)];
-    float* As = smem;
-    float* Bs = smem + 2 * BK * LDA;
+    constexpr int BM = 64, BN = 64, KQ = BK / 4;
+    constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
+    constexpr int AIN = A_PIECES / 256, BIN = B_PIECES / 256;       // DMA instructions per loader thread per chunk
+    __shared__ float4 smem[2 * STAGE];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool loader = wave >= 4;
-    const int phase = blockIdx.z;
+    int phase = blockIdx.z;
+    const float* seg0_ptr = p.seg[0].ptr;
+    const float* wbase = p.w;
+    const float* bias = p.bias;
+    float* outp = p.out;
+    if (p.ngroup == 2 && blockIdx.z == 1) { phase = 0; seg0_ptr = p.g1_seg0; wbase = p.g1_w; bias = p.g1_bias; outp = p.g1_out; }
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int T = p.ntap[phase];
     const int HoWo = p.Ho * p.Wo;
@@ -502,54 +291,59 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const pc_conv_params
     for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
     const int nchunks = T * chunks_per_tap;
 
-    if (loader) {
-        const int tid = threadIdx.x - 256;
-        const int kq = tid % KQ, arow0 = tid / KQ;
-        int a_iy0[AI], a_ix0[AI];
-        int64_t a_pix[AI];
-        bool a_ok[AI];
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ loader waves
+        const int lw = wave - 4;
+        int a_q[AIN]; int64_t a_pix[AIN]; uint32_t a_mask[AIN];
 #pragma unroll
-        for (int i = 0; i < AI; ++i) {
-            const int row = arow0 + i * ROWS_PER_PASS;
+        for (int i = 0; i < AIN; ++i) {
+            const int pa = (lw * AIN + i) * 64 + lane;
+            const int row = pa / KQ, slot = pa % KQ;
+            a_q[i] = slot ^ pc_swz<KQ>(row);
             const int m = m0 + row;
-            a_ok[i] = (row < BM) && (m < p.M);
-            const int mm = a_ok[i] ? m : 0;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
             const int b = mm / HoWo, r = mm - b * HoWo;
             const int oy = r / p.Wo, ox = r - oy * p.Wo;
-            a_iy0[i] = oy * p.stride;
-            a_ix0[i] = ox * p.stride;
-            a_pix[i] = ((int64_t)b * p.H + a_iy0[i]) * p.W + a_ix0[i];      // pixel index of tap (0,0)
-        }
-        const int b_n = (tid % BQ) * 4, bk0 = tid / BQ;
-        const bool b_nok = n0 + b_n < p.Cout, b_full = n0 + b_n + 3 < p.Cout;
-        int it_t = 0, it_s = 0, it_c = 0, it_cg = 0, it_sbase = 0;
-
-        auto load_chunk = [&](float4 (&ra)[AI], float4 (&rb)[BI]) {
-            const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
-            const int nch = p.seg[it_s].nch;
-            const int sld = p.seg[it_s].ld;
-            const float* sp = p.seg[it_s].ptr + (int64_t)(dy * p.W + dx) * sld + it_c + 4 * kq;
-            const bool kq_ok = it_c + 4 * kq < nch;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                const int iy = a_iy0[i] + dy, ix = a_ix0[i] + dx;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (kq_ok && a_ok[i] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    v = *reinterpret_cast<const float4*>(sp + a_pix[i] * sld);
-                if (p.square) { v.x *= v.x; v.y *= v.y; v.z *= v.z; v.w *= v.w; }
-                ra[i] = v;
+            const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+            a_pix[i] = ((int64_t)b * p.H + iy0) * p.W + ix0;
+            uint32_t mask = 0;
+            for (int t = 0; t < T; ++t) {
+                const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
+                if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
             }
-            const float* wrow = p.w + ((int64_t)p.wtap[phase][it_t] * p.Cin + it_cg) * p.Cout + n0 + b_n;
+            a_mask[i] = mask;
+        }
+        int b_q[BIN]; int64_t b_row[BIN]; bool b_ok[BIN];
 #pragma unroll
-            for (int i = 0; i < BI; ++i) {
-                const int k = bk0 + i * BROWS_PER_PASS;
-                float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < BK && it_c + k < nch && b_nok) {
-                    const float* wp = wrow + (int64_t)k * p.Cout;
-                    if (b_full) w = *reinterpret_cast<const float4*>(wp);
-                    else { w.x = wp[0]; if (n0 + b_n + 1 < p.Cout) w.y = wp[1]; if (n0 + b_n + 2 < p.Cout) w.z = wp[2]; }
-                }
-                rb[i] = w;
+        for (int i = 0; i < BIN; ++i) {
+            const int pb = (lw * BIN + i) * 64 + lane;
+            const int row = pb / KQ, slot = pb % KQ;
+            b_q[i] = slot ^ pc_swz<KQ>(row);
+            b_ok[i] = n0 + row < p.Cout;
+            b_row[i] = (int64_t)(n0 + row) * p.Cin;
+        }
+        int it_t = 0, it_s = 0, it_c = 0, it_cg = 0, it_sbase = 0;
+        auto issue = [&](int stage) {
+            const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
+            const int nch = p.seg[it_s].nch, sld = p.seg[it_s].ld;
+            const float* sp = (it_s == 0 ? seg0_ptr : p.seg[it_s].ptr) + (int64_t)(dy * p.W + dx) * sld + it_c;
+            const float* wp = wbase + (int64_t)p.wtap[phase][it_t] * p.Cout * p.Cin + it_cg;
+            float4* lds_a = smem + stage * STAGE + lw * AIN * 64;
+            float4* lds_b = smem + stage * STAGE + A_PIECES + lw * BIN * 64;
+#pragma unroll
+            for (int i = 0; i < AIN; ++i) {
+                const bool ok = ((a_mask[i] >> it_t) & 1u) && (it_c + 4 * a_q[i] < nch);
+                const float* src = ok ? sp + a_pix[i] * sld + 4 * a_q[i] : pc_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < BIN; ++i) {
+                const bool ok = b_ok[i] && (it_c + 4 * b_q[i] < nch);
+                const float* src = ok ? wp + b_row[i] + 4 * b_q[i] : pc_zero_page;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                                 (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16, 0, 0);
             }
             it_c += BK; it_cg += BK;
             if (it_c >= nch) {
@@ -557,133 +351,77 @@ __global__ __launch_bounds__(512) void conv_igemm_ws_kernel(const pc_conv_params
                 if (it_s >= p.nseg) { it_s = 0; it_sbase = 0; it_cg = 0; ++it_t; }
             }
         };
-        auto store_chunk = [&](int buf, const float4 (&ra)[AI], const float4 (&rb)[BI]) {
-            float* a = As + buf * BK * LDA;
-            float* b = Bs + buf * BK * LDB;
-#pragma unroll
-            for (int i = 0; i < AI; ++i) {
-                const int row = arow0 + i * ROWS_PER_PASS;
-                if (row < BM) {
-                    a[(kq * 4 + 0) * LDA + row] = ra[i].x;
-                    a[(kq * 4 + 1) * LDA + row] = ra[i].y;
-                    a[(kq * 4 + 2) * LDA + row] = ra[i].z;
-                    a[(kq * 4 + 3) * LDA + row] = ra[i].w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < BI; ++i) {
-                const int k = bk0 + i * BROWS_PER_PASS;
-                if (k < BK) *reinterpret_cast<float4*>(b + k * LDB + b_n) = rb[i];
-            }
-        };
-        float4 ra0[AI], rb0[BI], ra1[AI], rb1[BI];
-        if (p.dbg & 2) {                                   // ablation: barriers only
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                   // stage 0 landed
+        for (int c = 0; c < nchunks; ++c) {
+            if (c + 1 < nchunks) issue((c + 1) & 1);       // stage (c+1)&1 was last read in iteration c-1 (barrier passed)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            for (int c = 0; c < nchunks; ++c) __syncthreads();
-            return;
-        }
-        load_chunk(ra0, rb0);
-        if (nchunks > 1) load_chunk(ra1, rb1);
-        store_chunk(0, ra0, rb0);
-        __syncthreads();                                   // stage 0 ready
-        for (int c = 0;;) {
-            if (c + 2 < nchunks) load_chunk(ra0, rb0);
-            if (c + 1 < nchunks) store_chunk(1, ra1, rb1);
-            __syncthreads();
-            if (++c >= nchunks) break;
-            if (c + 2 < nchunks) load_chunk(ra1, rb1);
-            if (c + 1 < nchunks) store_chunk(0, ra0, rb0);
-            __syncthreads();
-            if (++c >= nchunks) break;
         }
         return;
     }
 
-    // ---- MFMA waves
-    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    // ---------------------------------------------------------------------- MFMA waves
+    const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    f32x16 acc[TM][TN];
+    const int am = wm * 32 + l31, bn = wn * 32 + l31;       // this lane's A row / B row inside the block tile
+    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);
+    f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-    auto compute = [&](int buf) {
-        // operands of G k-steps are read into registers one group ahead of the MFMAs that consume them, so the
-        // LDS latency of group g+1 hides behind the 64-cycle MFMAs of group g
-        constexpr int G = 8, NG = BK / (2 * G);
-        const float* a = As + buf * BK * LDA + wm * (TM * 32) + l31 + half * LDA;
-        const float* b = Bs + buf * BK * LDB + wn * (TN * 32) + l31 + half * LDB;
-        float av[2][G][TM], bv[2][G][TN];
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    auto compute = [&](int stage) {
+        const float4* A = smem + stage * STAGE + am * KQ;
+        const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
+        constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
+        float4 va0[2], va1[2], vb[2];
         auto rd = [&](int g, int slot) {
-#pragma unroll
-            for (int s = 0; s < G; ++s) {
-                const int kk = 2 * (g * G + s);
-#pragma unroll
-                for (int i = 0; i < TM; ++i) av[slot][s][i] = a[kk * LDA + i * 32];
-#pragma unroll
-                for (int j = 0; j < TN; ++j) bv[slot][s][j] = b[kk * LDB + j * 32];
-            }
+            va0[slot] = A[(2 * g) ^ a_swz];
+            va1[slot] = A[(2 * g + 1) ^ a_swz];
+            vb[slot] = Bp[(2 * g + half) ^ b_swz];
         };
         rd(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
-            __builtin_amdgcn_sched_barrier(0);     // keep the next group's LDS reads ahead of this group's MFMAs
-#pragma unroll
-            for (int s = 0; s < G; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g & 1][s][i], bv[g & 1][s][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const float4 x0 = va0[g & 1], x1 = va1[g & 1], y = vb[g & 1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.y : x0.x, y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.w : x0.z, y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.y : x1.x, y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.w : x1.z, y.w, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    __syncthreads();                                       // stage 0 ready
-    if (p.dbg & 1) {                                       // ablation: barriers only
-        for (int c = 0; c < nchunks; ++c) __syncthreads();
-    } else
-    for (int c = 0;;) {
-        compute(0);
+    __syncthreads();                                       // stage 0 landed
+    for (int c = 0; c < nchunks; ++c) {
+        compute(c & 1);
         __syncthreads();
-        if (++c >= nchunks) break;
-        compute(1);
-        __syncthreads();
-        if (++c >= nchunks) break;
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = m0 + wm * (TM * 32) + i * 32 + row;
-            if (m >= p.M) continue;
-            const int b = m / HoWo, rr = m - b * HoWo;
-            const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-            int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
-                if (n >= p.Cout) continue;
-                float v = acc[i][j][r];
-                if (p.bias) v = v + p.bias[n];
-                int nn = n, YY = Y, XX = X;
-                if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
-                const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
-                v = epilogue_value(p, v, pix, nn);
-                p.out[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
-            }
-        }
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        const int m = m0 + wm * 32 + row;
+        if (m >= p.M) continue;
+        const int b = m / HoWo, rr = m - b * HoWo;
+        const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+        const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
+        const int n = n0 + wn * 32 + l31;
+        if (n >= p.Cout) continue;
+        float v = acc[r];
+        if (bias) v = v + bias[n];
+        int nn = n, YY = Y, XX = X;
+        if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
+        const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
+        v = epilogue_value(p, v, pix, nn);
+        outp[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
     }
 }
 
-template <int TM, int TN, int BK>
-hipError_t launch_ws(const pc_conv_params& p, hipStream_t stream)
+template <int BK>
+hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.nphase);
-    hipLaunchKernelGGL((conv_igemm_ws_kernel<TM, TN, BK>), grid, dim3(512), 0, stream, p);
+    dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, p.ngroup == 2 ? 2 : p.nphase);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -696,6 +434,12 @@ hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
 }
 
 }  // namespace
+
+int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
+{
+    const long ktot = (long)(kind == 0 ? k * k : 9) * Cin;     // largest K of any output phase
+    return (Cin % 16 == 0 && Cout > 4 && ktot > 256) ? 1 : 0;
+}
 
 // Host-side validation + tile selection.  Returns a pc status code.
 int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
@@ -717,42 +461,29 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         if (p.ntap[ph] < 1 || p.ntap[ph] > PC_MAX_TAP) return PC_ERR_ARG;
     if (p.pixel_shuffle && (p.Cout % 4)) return PC_ERR_ARG;
 
-    // Tile / K-loop selection (measured on MI355X, tools/conv_tune.py, profiles/r01_*):
-    //  * 64x64 block tiles win everywhere except the 3-channel output layer;
-    //  * with >= 4 blocks per CU the low-register BK=16 loop is fastest (occupancy hides the per-chunk
-    //    barrier); with fewer blocks (the M = 8192 slice-chain GEMMs) the BK=32 / prefetch-distance-2 loop is.
-    int cfg = p.tile_cfg;
-    static const int impl_env = [] { const char* v = std::getenv("PC_CONV_IMPL"); return v ? std::atoi(v) : 0; }();
-    if (cfg == PC_TILE_AUTO) cfg = (p.Cout <= 4) ? PC_TILE_128x32 : PC_TILE_64x64;
-    const int bm = cfg == PC_TILE_64x64 ? 64 : 128, bn = cfg == PC_TILE_128x128 ? 128 : (cfg == PC_TILE_64x64 ? 64 : 32);
-    const long blocks = (long)((p.M + bm - 1) / bm) * ((p.Cout + bn - 1) / bn) * p.nphase;
-    long ktot = 0;
-    for (int ph = 0; ph < p.nphase; ++ph) ktot = std::max<long>(ktot, (long)p.ntap[ph] * p.Cin);
-    //  * wave-specialised 64x64 kernel (4 MFMA + 4 loader waves) for every layer with a real K loop; K-chunk 64 when
-    //    the grid is small (the loaders then need the longer MFMA phase to cover a global-load round trip);
-    //  * the plain BK=16 kernel for K <= 256 (1x1 convs / GDN: epilogue-dominated) and for the 3-channel output layer.
-    int impl = impl_env ? impl_env : ((ktot <= 256 || cfg != PC_TILE_64x64) ? 1 : 4);
+    // Kernel selection (measured on MI355X with tools/conv_tune.py; profiles/r01_*):
+    //  * weight layout 1 (chosen at pack time by pc_conv_weight_layout: K per phase > 256, Cout > 4, Cin % 16 == 0):
+    //    wave-specialised 64x64 LDS-DMA kernel; K-chunk 64 when the grid is small (slice-chain GEMMs), else 32;
+    //  * weight layout 0: the plain BK=16 kernel (1x1 convs / GDN: epilogue-dominated; the 3-channel output layer;
+    //    the 3-channel input layer through the element-gather loader).
     hipError_t e;
-    if (!p.smallc && impl == 4) {
+    if (p.wlayout == 1) {
+        if (p.smallc || p.square || (p.Cin % 16)) return PC_ERR_ARG;
+        if (p.ngroup == 2 && (p.nphase != 1 || !p.g1_seg0 || !p.g1_w || !p.g1_out)) return PC_ERR_ARG;
+        long ktot = 0;
+        for (int ph = 0; ph < p.nphase; ++ph) ktot = std::max<long>(ktot, (long)p.ntap[ph] * p.Cin);
+        const long blocks = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
         static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
         const int bk = bk_env ? bk_env : ((blocks < 1024 && ktot >= 1024) ? 64 : 32);
-        switch (cfg) {
-        case PC_TILE_128x128: e = launch_ws<2, 2, 32>(p, stream); break;
-        case PC_TILE_64x64: e = bk == 64 ? launch_ws<1, 1, 64>(p, stream) : launch_ws<1, 1, 32>(p, stream); break;
-        default: return PC_ERR_ARG;
-        }
-    } else if (p.smallc || impl == 1) {
+        e = bk == 64 ? launch_dma<64>(p, stream) : launch_dma<32>(p, stream);
+    } else {
+        if (p.ngroup == 2) return PC_ERR_ARG;
+        int cfg = p.tile_cfg;
+        if (cfg == PC_TILE_AUTO) cfg = (p.Cout <= 4) ? PC_TILE_128x32 : PC_TILE_64x64;
         switch (cfg) {
         case PC_TILE_128x128: e = p.smallc ? launch_cfg<128, 128, 2, 2, true>(p, stream) : launch_cfg<128, 128, 2, 2, false>(p, stream); break;
         case PC_TILE_64x64: e = p.smallc ? launch_cfg<64, 64, 2, 2, true>(p, stream) : launch_cfg<64, 64, 2, 2, false>(p, stream); break;
         case PC_TILE_128x32: e = p.smallc ? launch_cfg<128, 32, 4, 1, true>(p, stream) : launch_cfg<128, 32, 4, 1, false>(p, stream); break;
-        default: return PC_ERR_ARG;
-        }
-    } else {
-        switch (cfg) {
-        case PC_TILE_128x128: e = launch_cfg2<128, 128, 2, 2, 32>(p, stream); break;
-        case PC_TILE_64x64: e = launch_cfg2<64, 64, 2, 2, 32>(p, stream); break;
-        case PC_TILE_128x32: e = launch_cfg2<128, 32, 4, 1, 32>(p, stream); break;
         default: return PC_ERR_ARG;
         }
     }

@@ -45,8 +45,9 @@ struct pc_conv_params {
     int8_t dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
     int wtap[4][PC_MAX_TAP];                 // weight tap index
     int stride;
-    // weights [ntaps][Cin][Cout], bias [Cout] or null
+    // weights: layout 0 = [ntaps][Cin][Cout]; layout 1 = [ntaps][Cout][Cin], k permuted in groups of 8 (pc_conv.hip)
     const float* w;
+    int wlayout;
     const float* bias;
     int Cout;
     // output grid per phase and mapping into the output tensor
@@ -61,10 +62,16 @@ struct pc_conv_params {
     const float* aux0; int ld0;
     const float* aux1; int ld1;
     int tile_cfg;
+    // grouped launch: a second GEMM of identical shape (cc_mean || cc_scale of one chain step) rides on blockIdx.z == 1;
+    // it differs only in its first input segment, weights, bias and output
+    int ngroup;
+    const float* g1_seg0; const float* g1_w; const float* g1_bias; float* g1_out;
     int dbg;                                 // tuning ablations only (PC_CONV_DBG): 1 = skip MFMA, 2 = skip loader work
 };
 
 int pc_conv_launch(const pc_conv_params& p, hipStream_t stream);
+// weight layout the launcher expects for a layer (kind 0 conv / 1 transposed conv k5 s2)
+int pc_conv_weight_layout(int kind, int Cin, int Cout, int k);
 
 // window attention core
 int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int ws,
