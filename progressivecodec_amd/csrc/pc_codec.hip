@@ -843,7 +843,7 @@ int ensure_lanes(pc_codec* c, int n)
 int lane_count(const pc_codec* c, int B)
 {
     static const int env = [] { const char* v = std::getenv("PC_LANES"); return v ? std::atoi(v) : 0; }();
-    int n = env > 0 ? env : 2;
+    int n = env > 0 ? env : 2;          // measured: 1 lane 93.0 ms, 2 lanes 91.6 ms, 4 lanes slower (Config 2)
     if (c->profile) n = 1;
     return std::max(1, std::min(n, std::min(B, 8)));
 }

@@ -269,12 +269,14 @@ __device__ __attribute__((aligned(64))) float pc_zero_page[16];
 
 template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
 
-template <int BK>
-__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_params p)
+template <int BK, int BN, int TM>
+__global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(const pc_conv_params p)
 {
-    constexpr int BM = 64, BN = 64, KQ = BK / 4;
+    constexpr int BM = 64 * TM, KQ = BK / 4;             // each MFMA wave owns TM row-tiles of 32x32
+    constexpr int NMW = 2 * (BN / 32);                    // MFMA waves (2 x BN/32 tiles of 32x32); as many loader waves
+    constexpr int NLT = NMW * 64;                         // loader threads
     constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
-    constexpr int AIN = A_PIECES / 256, BIN = B_PIECES / 256;       // DMA instructions per loader thread per chunk
+    constexpr int AIN = A_PIECES / NLT, BIN = B_PIECES / NLT;       // DMA instructions per loader thread per chunk
     __shared__ float4 smem[2 * STAGE];
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -291,9 +293,9 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
     for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
     const int nchunks = T * chunks_per_tap;
 
-    if (wave >= 4) {
+    if (wave >= NMW) {
         // ------------------------------------------------------------------ loader waves
-        const int lw = wave - 4;
+        const int lw = wave - NMW;
         int a_q[AIN]; int64_t a_pix[AIN]; uint32_t a_mask[AIN];
 #pragma unroll
         for (int i = 0; i < AIN; ++i) {
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // stage 0 landed
         for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks) issue((c + 1) & 1);       // stage (c+1)&1 was last read in iteration c-1 (barrier passed)
+            if (c + 1 < nchunks && !(p.dbg & 2)) issue((c + 1) & 1);       // stage (c+1)&1 was last read in iteration c-1 (barrier passed)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -363,21 +365,26 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
     }
 
     // ---------------------------------------------------------------------- MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = BN == 64 ? (wave >> 1) : wave, wn = BN == 64 ? (wave & 1) : 0;
     const int half = lane >> 5, l31 = lane & 31;
-    const int am = wm * 32 + l31, bn = wn * 32 + l31;       // this lane's A row / B row inside the block tile
-    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);
-    f32x16 acc;
+    const int am = wm * (32 * TM) + l31, bn = wn * 32 + l31;   // this lane's first A row / B row inside the block tile
+    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);  // (32-row steps keep the swizzle of a lane unchanged)
+    f32x16 acc[TM];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
     auto compute = [&](int stage) {
         const float4* A = smem + stage * STAGE + am * KQ;
         const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
         constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
-        float4 va0[2], va1[2], vb[2];
+        float4 va0[2][TM], va1[2][TM], vb[2];
         auto rd = [&](int g, int slot) {
-            va0[slot] = A[(2 * g) ^ a_swz];
-            va1[slot] = A[(2 * g + 1) ^ a_swz];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                va0[slot][i] = A[i * 32 * KQ + ((2 * g) ^ a_swz)];
+                va1[slot][i] = A[i * 32 * KQ + ((2 * g + 1) ^ a_swz)];
+            }
             vb[slot] = Bp[(2 * g + half) ^ b_swz];
         };
         rd(0, 0);
@@ -385,29 +392,38 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 x0 = va0[g & 1], x1 = va1[g & 1], y = vb[g & 1];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.y : x0.x, y.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.w : x0.z, y.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.y : x1.x, y.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.w : x1.z, y.w, acc, 0, 0, 0);
+            const float4 y = vb[g & 1];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const float4 x0 = va0[g & 1][i], x1 = va1[g & 1][i];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.y : x0.x, y.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.w : x0.z, y.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.y : x1.x, y.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.w : x1.z, y.w, acc[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // an MFMA wave whose 32 columns all lie beyond Cout (N tails: 224, 176, 160, 96, 32 ...) only keeps the barriers
+    const bool live = (n0 + wn * 32 < p.Cout) && !(p.dbg & 1);
     __syncthreads();                                       // stage 0 landed
     for (int c = 0; c < nchunks; ++c) {
-        compute(c & 1);
+        if (live) compute(c & 1);
         __syncthreads();
     }
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = m0 + wm * 32 + row;
+        const int m = m0 + wm * (32 * TM) + i * 32 + row;
         if (m >= p.M) continue;
         const int b = m / HoWo, rr = m - b * HoWo;
         const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
         const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
         const int n = n0 + wn * 32 + l31;
         if (n >= p.Cout) continue;
-        float v = acc[r];
+        float v = acc[i][r];
         if (bias) v = v + bias[n];
         int nn = n, YY = Y, XX = X;
         if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
@@ -417,11 +433,12 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
     }
 }
 
-template <int BK>
+template <int BK, int BN, int TM>
 hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
-    dim3 grid((p.M + 63) / 64, (p.Cout + 63) / 64, p.ngroup == 2 ? 2 : p.nphase);
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK>), grid, dim3(512), 0, stream, p);
+    constexpr int BM = 64 * TM;
+    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ngroup == 2 ? 2 : p.nphase);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK, BN, TM>), grid, dim3(BN == 64 ? 512 : 256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -474,8 +491,10 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         for (int ph = 0; ph < p.nphase; ++ph) ktot = std::max<long>(ktot, (long)p.ntap[ph] * p.Cin);
         const long blocks = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
         static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
+        // variants measured and rejected (tools/conv_tune.py, profiles/r01_tune_*.log): 64x32 and 128x64 block tiles,
+        // register-staged loaders (plain, prefetch distance 2, and with the even/odd k split done by the loader)
         const int bk = bk_env ? bk_env : ((blocks < 1024 && ktot >= 1024) ? 64 : 32);
-        e = bk == 64 ? launch_dma<64>(p, stream) : launch_dma<32>(p, stream);
+        e = bk == 64 ? launch_dma<64, 64, 1>(p, stream) : launch_dma<32, 64, 1>(p, stream);
     } else {
         if (p.ngroup == 2) return PC_ERR_ARG;
         int cfg = p.tile_cfg;

@@ -77,6 +77,9 @@ CONV_CASES = [
     (2, 16, 16, 192, 192, 5, 2, 0, 3),   # forced 128x32
     (1, 1, 1, 224, 192, 3, 2, 0, 0),     # M = 1 (64x64 image hyper-analysis tail)
     (2, 32, 32, 3, 192, 5, 2, 0, 0),     # first layer: Cin = 3 element-wise gather path
+    (8, 64, 64, 96, 96, 3, 1, 1, 0),     # >= 1024 blocks: K-chunk 32 LDS-DMA kernel, N tail 96 = 64 + 32
+    (4, 16, 16, 640, 320, 1, 1, 0, 0),   # 1x1 with K = 640 (LDS-DMA kernel, 10 chunks)
+    (2, 16, 16, 160, 160, 3, 1, 1, 0),   # Cin = 160: K-chunk 64 with a 32-channel segment tail
 ]
 
 
