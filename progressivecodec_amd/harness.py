@@ -1,0 +1,59 @@
+"""compress_with_ac -- the reference's end-to-end real-bitstream harness
+(/root/reference/src/compress/training/step.py:277-404), restated for in-memory images.
+
+Per image: centre zero-pad to a multiple of 64 (step.py:318-319, compressai.ops.compute_padding),
+for every level `p` of `pr_list`: compress -> decompress (only the decode is timed, step.py:332-340),
+un-pad and clamp (step.py:342-343), PSNR = -10 log10(mean((x - x_hat)^2)) (step.py:13-18,349),
+bpp = 8 * (sum of the byte-string lengths) / (H*W) over the UNPADDED size (step.py:357-365).
+File reading, MS-SSIM, wandb logging and the text dump of step.py are outside the hot path.
+"""
+import math
+import time
+
+#: the level list the authors evaluate (train.py:293)
+PR_LIST = [0, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.25, 2, 3, 5, 10]
+
+
+def compute_padding(in_h, in_w, min_div=64):
+    out_h = (in_h + min_div - 1) // min_div * min_div
+    out_w = (in_w + min_div - 1) // min_div * min_div
+    left = (out_w - in_w) // 2
+    right = out_w - in_w - left
+    top = (out_h - in_h) // 2
+    bottom = out_h - in_h - top
+    return (left, right, top, bottom), (-left, -right, -top, -bottom)
+
+
+def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda"):
+    """images: iterable of [1,3,H,W] (or [3,H,W]) float tensors in [0,1].
+    Returns (bpp[level], psnr[level], dec_time[level]) averaged over the images, as step.py:404 does,
+    plus the per-image table."""
+    import torch
+    import torch.nn.functional as F
+    pr_list = list(PR_LIST if pr_list is None else pr_list)
+    rows = []
+    with torch.no_grad():
+        for x in images:
+            x = x if x.dim() == 4 else x.unsqueeze(0)
+            x = x.to(device)
+            h, w = x.shape[2:]
+            pad, unpad = compute_padding(h, w, 64)
+            x_padded = F.pad(x, pad, mode="constant", value=0)
+            for p in pr_list:
+                data = model.compress(x_padded, quality=p, mask_pol=mask_pol)
+                if x.is_cuda:
+                    torch.cuda.synchronize()
+                t0 = time.time()
+                out_dec = model.decompress(data["strings"], data["shape"], quality=p, mask_pol=mask_pol)
+                if x.is_cuda:
+                    torch.cuda.synchronize()
+                dec_time = time.time() - t0
+                x_hat = F.pad(out_dec["x_hat"], unpad).clamp_(0, 1)
+                mse = torch.mean((x - x_hat) ** 2).item()
+                psnr = -10.0 * math.log10(mse) if mse > 0 else float("inf")
+                y_strings, z_strings = data["strings"]
+                nbytes = sum(len(s[0]) for s in y_strings) + sum(len(s) for s in z_strings)   # step.py:357-365 (B = 1)
+                rows.append({"quality": p, "bpp": 8.0 * nbytes / (h * w), "psnr": psnr, "dec_time": dec_time})
+    n_img = max(1, len(rows) // max(1, len(pr_list)))
+    avg = lambda key, p: sum(r[key] for r in rows if r["quality"] == p) / n_img
+    return ([avg("bpp", p) for p in pr_list], [avg("psnr", p) for p in pr_list], [avg("dec_time", p) for p in pr_list], rows)
