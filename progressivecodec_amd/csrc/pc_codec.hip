@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <new>
 #include <cmath>
 #include <cstdio>
@@ -97,6 +98,7 @@ struct pc_codec {
     std::vector<Lane> lanes;
     hipEvent_t eFork = nullptr;
     std::mutex buf_mu;
+    double t_host_decode_ms = 0.0;
     // last-call geometry for taps
     int last_B = 0, last_h16 = 0, last_w16 = 0;
 
@@ -950,8 +952,10 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
                                       c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA));
         HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
         HIPCHK(hipStreamSynchronize(sA));
+        const auto td0 = std::chrono::steady_clock::now();
         PCCHK(pc_rans_decode_batch(y_strings + (size_t)step * k.B + b0, y_lens + (size_t)step * k.B + b0, nb, h_idx, per,
                                    c->gc.cdf.data(), c->gc.n, c->gc.stride, c->gc.len.data(), c->gc.off.data(), h_sym, nt));   // :894,969
+        { std::lock_guard<std::mutex> lk(c->buf_mu); c->t_host_decode_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); }
         HIPCHK(hipMemcpyAsync(k.sym + so, h_sym, per * nb * 4, hipMemcpyHostToDevice, sA));
         float* dst = e ? img(k.ye, b0, pi * D0) + 32 * i : img(k.yb, b0, pi * D0) + 32 * i;
         PCCHK(pc_gc_dequantize(k.sym + so, k.mu + so, SLICE, nb, k.HW, dst, D0, sA));                                          // :896,971
@@ -1054,6 +1058,9 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :702-704
     PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :705-715
     PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :729-845
+    static const bool timing = std::getenv("PC_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_launch = now();
 
     // ---- symbols/indexes to the host, rANS on the thread pool  (entropy_models.py:226-235)
     const size_t n_y = (size_t)n_slices * M * SLICE, n_z = (size_t)B * ZHW * NCH;
@@ -1062,6 +1069,7 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_y * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_sym + n_y, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    const double t_sync = now();
     for (size_t e = 0; e < n_z; ++e) c->h_idx[n_y + e] = (int32_t)((e / ZHW) % NCH);     // EntropyBottleneck._build_indexes :492-502
     c->res_slices = n_slices; c->res_B = B;
     c->y_strings.assign((size_t)n_slices * B, {});
@@ -1084,6 +1092,8 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     const size_t n_jobs = (size_t)n_slices * B + B;
     if (c->n_threads == 1) for (size_t j = 0; j < n_jobs; ++j) job(j);
     else pc::default_pool().parallel_for(n_jobs, job);
+    if (timing) std::fprintf(stderr, "[pcodec] compress: launches done -> GPU+D2H done %.2f ms, host rANS encode %.2f ms (%zu streams)\n",
+                             t_sync - t_launch, now() - t_sync, n_jobs);
     return rc;
 }
 
@@ -1132,7 +1142,9 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
     PCCHK(pc_eb_dequant_launch(z_sym, B, ZHW, NCH, c->medians, z_hat, st));
     HIPCHK(hipStreamSynchronize(st));   // h_sym is reused by the lanes
     PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :856-867
+    c->t_host_decode_ms = 0.0;
     PCCHK(run_chain(k, st, true, y_strings, y_lens));                                    // :874-983
+    if (std::getenv("PC_TIMING")) std::fprintf(stderr, "[pcodec] decompress: host rANS decode (summed over lanes) %.2f ms\n", c->t_host_decode_ms);
     PCCHK(g_s(c, st, c->gs[k.enh ? 1 : 0], k.enh ? k.ye : k.yb, B, h, w, x_hat));       // :907-916 / :986-990
     return PC_OK;
 }
