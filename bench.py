@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-images", type=int, default=2)
+    ap.add_argument("--cpu-images", type=int, default=32, help="images of rank 0's batch the CPU port codes (x2 repetitions)")
     args = ap.parse_args()
 
     import torch
@@ -187,15 +187,17 @@ def main():
         orc.update()
         n_img = max(1, args.cpu_images)
         xc = x[:n_img].cpu()
+        reps = 2
         t0 = time.perf_counter()
         with torch.no_grad():
-            o = orc.compress(xc, q)
-            d = orc.decompress(o["strings"], o["shape"], q)
+            for _ in range(reps):
+                o = orc.compress(xc, q)
+                d = orc.decompress(o["strings"], o["shape"], q)
         dt = time.perf_counter() - t0
         pairs = [(a[i], b[i]) for a, b in zip(out["strings"][0], o["strings"][0]) for i in range(n_img)]
         same = sum(a == b for a, b in pairs)
-        line["cpu_baseline"] = {"value": round(n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
-                                "sample": f"{n_img} of the {B} images of rank 0 ({S}x{S}, q={q}), encode+decode once, "
+        line["cpu_baseline"] = {"value": round(reps * n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
+                                "sample": f"{n_img} of the {B} images of rank 0 ({S}x{S}, q={q}) as one batch, encode+decode x{reps}, "
                                           f"torch {torch.__version__} CPU ops + C rANS, {dt:.1f} s",
                                 "y_strings_identical_to_gpu": f"{same}/{len(pairs)}"}
     if rank == 0:
