@@ -89,8 +89,8 @@ PC_API int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint3
 /* Generic convolution / transposed convolution / linear layer with the reference's weight layout.
  *   kind 0: nn.Conv2d weight [Cout][Cin][k][k], stride s, padding k/2   (models/utils.py:186, layers/layers.py:15,27)
  *   kind 1: nn.ConvTranspose2d(k=5, s=2, p=2, output_padding=1) weight [Cin][Cout][5][5]   (models/utils.py:196)
- * `w_packed` must come from pc_pack_conv_weight (tap-major; the layout -- [taps][Cin][Cout], or [taps][Cout][Cin] with the
- * channels of each aligned group of 8 permuted for the LDS-DMA kernel -- is a function of (kind, Cin, Cout, k) only).
+ * `w_packed` must come from pc_pack_conv_weight (tap-major; the layout -- [taps][Cin][Cout] or [taps][Cout][Cin] -- is a
+ * function of (kind, Cin, Cout, k) only).
  * act: 0 none, 1 GELU.  x: [B][H][W][Cin], out: [B][Ho][Wo][Cout]. */
 PC_API int pc_pack_conv_weight(const float* w_host, int kind, int Cout, int Cin, int k, float* w_packed_host);
 PC_API int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin,

@@ -10,8 +10,10 @@
  *      quantile mask, quantise);
  *  (2) the float32 network primitives evaluated in the *defined summation order*
  *      of the bitstream contract (DESIGN.md "numeric contract"): every output
- *      element is one fmaf chain over (tap, input-channel) ascending, starting at
- *      +0, bias added afterwards; transcendental functions from include/pc_math.h.
+ *      element is one fmaf chain over the flattened index k = tap*Cin + channel,
+ *      taken in aligned groups of 8 with the in-group order 0,4,1,5,2,6,3,7,
+ *      starting at +0, bias added afterwards; transcendental functions from
+ *      include/pc_math.h.
  *      The HIP kernels implement the same chains on the f32 MFMA pipe, so GPU and
  *      oracle agree bit-for-bit.  Against the PyTorch reference these agree to
  *      float rounding (tests/test_oracle_vs_golden.py); PyTorch's own oneDNN order
@@ -283,9 +285,12 @@ ORC_API void orc_unary(float *x, int64_t n, int op)
 
 /* Generic "tap list" convolution over NHWC activations:
  *   out[b, i*osy+ooy, j*osx+oox, n] = sum_{t<T} sum_{c<Cin} f(x[b, i*stride+dy[t], j*stride+dx[t], c]) * w[t][c][n]
- * evaluated per output element as ONE fmaf chain in (t, c) ascending order from +0
- * (taps falling outside the image contribute a = 0, which leaves the chain's value
- * unchanged).  f = identity, or x*x when square != 0 (GDN: F.conv2d(x**2, gamma), gdn.py:56).
+ * evaluated per output element as ONE fmaf chain from +0 over the flattened index
+ * k = t*Cin + c, in aligned groups of 8 visited in the in-group order 0,4,1,5,2,6,3,7
+ * (the order in which a 64-lane f32 MFMA consumes two adjacent 16-byte k-quads: lanes 0-31
+ * carry the first quad, lanes 32-63 the second, and one MFMA adds its lane-half-0 product
+ * before its lane-half-1 product); indices past the end of K are skipped; taps falling
+ * outside the image contribute a = 0, which leaves the chain's value unchanged.  f = identity, or x*x when square != 0 (GDN: F.conv2d(x**2, gamma), gdn.py:56).
  * Covers nn.Conv2d 5x5 s2 / 3x3 s1,s2 / 1x1 (models/utils.py:186, layers.py:15,27), nn.Linear
  * (1 tap) and each output phase of ConvTranspose2d(5, s2, p2, op1) (models/utils.py:196).
  * No bias: the caller adds it afterwards (one float add), as the contract says. */
@@ -296,6 +301,16 @@ ORC_API void orc_conv_nhwc(const float *x, int B, int H, int W, int Cin, int ldx
                            int square)
 {
     float *zeros = (float *)calloc((size_t)Cin, sizeof(float));
+    /* the chain order: flattened k in aligned groups of 8, in-group order 0,4,1,5,2,6,3,7 */
+    static const int perm8[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    const int K = T * Cin;
+    int *ord_t = (int *)malloc(sizeof(int) * (size_t)K), *ord_c = (int *)malloc(sizeof(int) * (size_t)K);
+    int nord = 0;
+    for (int g = 0; g < K; g += 8)
+        for (int j = 0; j < 8; ++j) {
+            const int kf = g + perm8[j];
+            if (kf < K) { ord_t[nord] = kf / Cin; ord_c[nord] = kf % Cin; ++nord; }
+        }
     const int64_t rows = (int64_t)B * Ho;
 #pragma omp parallel for schedule(dynamic, 1)
     for (int64_t r = 0; r < rows; ++r) {
@@ -317,12 +332,12 @@ ORC_API void orc_conv_nhwc(const float *x, int B, int H, int W, int Cin, int ldx
             int n0 = 0;
             for (; n0 + 16 <= Cout; n0 += 16) {
                 __m256 a00 = _mm256_setzero_ps(), a01 = a00, a10 = a00, a11 = a00, a20 = a00, a21 = a00, a30 = a00, a31 = a00;
-                for (int t = 0; t < T; ++t) {
-                    const float *wt = w + ((int64_t)t * Cin) * Cout + n0;
-                    const float *x0 = xp[0][t], *x1 = xp[1][t], *x2 = xp[2][t], *x3 = xp[3][t];
-                    for (int c = 0; c < Cin; ++c) {
-                        const __m256 w0 = _mm256_loadu_ps(wt + (int64_t)c * Cout), w1 = _mm256_loadu_ps(wt + (int64_t)c * Cout + 8);
-                        float v0 = x0[c], v1 = x1[c], v2 = x2[c], v3 = x3[c];
+                for (int o = 0; o < nord; ++o) {
+                    {
+                        const int t = ord_t[o], c = ord_c[o];
+                        const float *wt = w + ((int64_t)t * Cin + c) * Cout + n0;
+                        const __m256 w0 = _mm256_loadu_ps(wt), w1 = _mm256_loadu_ps(wt + 8);
+                        float v0 = xp[0][t][c], v1 = xp[1][t][c], v2 = xp[2][t][c], v3 = xp[3][t][c];
                         if (square) { v0 *= v0; v1 *= v1; v2 *= v2; v3 *= v3; }
                         const __m256 b0 = _mm256_set1_ps(v0), b1 = _mm256_set1_ps(v1), b2 = _mm256_set1_ps(v2), b3 = _mm256_set1_ps(v3);
                         a00 = _mm256_fmadd_ps(b0, w0, a00); a01 = _mm256_fmadd_ps(b0, w1, a01);
@@ -339,21 +354,18 @@ ORC_API void orc_conv_nhwc(const float *x, int B, int H, int W, int Cin, int ldx
             for (; n0 < Cout; ++n0) {        /* scalar tail (Cout = 3, or Cout % 16) */
                 for (int p = 0; p < P; ++p) {
                     float acc = 0.0f;
-                    for (int t = 0; t < T; ++t) {
-                        const float *wt = w + ((int64_t)t * Cin) * Cout + n0;
-                        const float *xx = xp[p][t];
-                        for (int c = 0; c < Cin; ++c) {
-                            float v = xx[c];
-                            if (square) v *= v;
-                            acc = fmaf(v, wt[(int64_t)c * Cout], acc);
-                        }
+                    for (int o = 0; o < nord; ++o) {
+                        const int t = ord_t[o], c = ord_c[o];
+                        float v = xp[p][t][c];
+                        if (square) v *= v;
+                        acc = fmaf(v, w[((int64_t)t * Cin + c) * Cout + n0], acc);
                     }
                     op[p][n0] = acc;
                 }
             }
         }
     }
-    free(zeros);
+    free(zeros); free(ord_t); free(ord_c);
 }
 
 /* Shifted-window multi-head self-attention core (between the qkv and proj Linears):

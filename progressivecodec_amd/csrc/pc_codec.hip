@@ -570,15 +570,12 @@ extern "C" int pc_pack_conv_weight(const float* w, int kind, int Cout, int Cin, 
                     for (int co = 0; co < Cout; ++co) dst[co] = src(co, ci, ky, kx);
                 }
     } else {
-        // layout 1: [ky*k+kx][Cout][Cin], channels permuted inside aligned groups of 8 to (0,2,4,6,1,3,5,7)
+        // layout 1: [ky*k+kx][Cout][Cin]  (K contiguous per output channel: 16-byte k-quads for the LDS-DMA kernel)
         for (int ky = 0; ky < k; ++ky)
             for (int kx = 0; kx < k; ++kx)
                 for (int co = 0; co < Cout; ++co) {
                     float* dst = out + (((size_t)(ky * k + kx) * Cout) + co) * Cin;
-                    for (int ci = 0; ci < Cin; ++ci) {
-                        const int r = ci & 7;
-                        dst[(ci & ~7) + (r >> 1) + 4 * (r & 1)] = src(co, ci, ky, kx);
-                    }
+                    for (int ci = 0; ci < Cin; ++ci) dst[ci] = src(co, ci, ky, kx);
                 }
     }
     return PC_OK;

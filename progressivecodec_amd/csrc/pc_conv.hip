@@ -13,10 +13,11 @@
 // K-chunk (one tap x 16 channels) is 64 contiguous bytes per pixel; the channel axis of the
 // input may be a *virtual concatenation* of up to 8 segments (no torch.cat copies in the
 // 20-step slice chain).  Numeric contract (include/pc_math.h): each output
-// element is ONE fmaf chain over (tap, channel) ascending starting at +0 -- exactly what
-// v_mfma_f32_32x32x2_f32 computes when the K loop feeds it in order and nothing is split
-// along K -- so results are bit-identical for every tile shape, batch size and device, and
-// equal to oracle/pc_oracle.c:orc_conv_nhwc.
+// element is ONE fmaf chain starting at +0 over the flattened index k = tap*Cin + channel,
+// in aligned groups of 8 visited as 0,4,1,5,2,6,3,7 -- what v_mfma_f32_32x32x2_f32 computes
+// when lanes 0-31 / 32-63 carry the two 16-byte quads of a group and nothing is split along
+// K -- so results are bit-identical for every tile shape, batch size and device, and equal
+// to oracle/pc_oracle.c:orc_conv_nhwc.
 //
 // Tiling: 256 threads = 4 waves (64 lanes); block tile BM x BN; K-chunk 16; each wave owns
 // TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); A/B chunks are register-staged
@@ -208,12 +209,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
         const float* a = As + cur * BK * LDA + wm * (TM * 32) + l31;
         const float* b = Bs + cur * BK * LDB + wn * (TN * 32) + l31;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
+        for (int st = 0; st < BK / 2; ++st) {
+            // chain order of the contract: aligned groups of 8 k, in-group order 0,4,1,5,2,6,3,7 -- MFMA step s of a
+            // group takes k = s (lanes 0-31) and k = s + 4 (lanes 32-63)
+            const int kk = (st >> 2) * 8 + (st & 3) + 4 * half;
             float av[TM], bv[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = a[(kk + half) * LDA + i * 32];
+            for (int i = 0; i < TM; ++i) av[i] = a[kk * LDA + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = b[(kk + half) * LDB + j * 32];
+            for (int j = 0; j < TN; ++j) bv[j] = b[kk * LDB + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -261,11 +265,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // `global_load_lds_dwordx4` (16 B per lane straight into LDS, no VGPR staging, no ds_write) plus a
 // few address ops; the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE
 // address (LDS-DMA writes lane-linearly), read back conflict-free with ds_read_b128; weights are
-// pre-packed [tap][Cout][Cin] with k permuted inside aligned groups of 8 to (0,2,4,6,1,3,5,7) so a B
-// lane fetches its four next k in ONE 16-byte read.  Per 4 MFMAs an MFMA wave issues 3 ds_read_b128
-// and 4 v_cndmask.  Same fmaf chains (k ascending) as every other variant.
+// pre-packed [tap][Cout][Cin] (K contiguous per output channel).  The contract's chain order inside an
+// aligned group of 8 k (0,4,1,5,2,6,3,7) is exactly what the MFMA computes when lanes 0-31 hold the
+// group's first 16-byte quad and lanes 32-63 its second: per 4 MFMAs an MFMA wave issues 2
+// ds_read_b128 and no VALU (an earlier k-ascending contract needed 3 reads + 4 v_cndmask per 4 MFMAs:
+// 22 % slower, PC_CONV_DBG ablation in profiles/r01_tune_tune12.log).
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) float pc_zero_page[16];
+// diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop phases, [block][8]
+__device__ unsigned long long pc_dbg_stamps[8192][8];
 
 template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
 
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
     constexpr int NLT = NMW * 64;                         // loader threads
     constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
     constexpr int AIN = A_PIECES / NLT, BIN = B_PIECES / NLT;       // DMA instructions per loader thread per chunk
-    __shared__ float4 smem[2 * STAGE];
+    __shared__ float4 smem[2 * STAGE + PC_MAX_TAP * PC_MAX_SEG * 2];   // two stages + the (tap, segment) run table
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int phase = blockIdx.z;
@@ -295,6 +303,10 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
 
     if (wave >= NMW) {
         // ------------------------------------------------------------------ loader waves
+        // The loaders issue ~30 instructions per chunk; at default priority they only got an issue slot about once per
+        // MFMA of their SIMD partner (stamps: loader issue time == MFMA phase + 200 cycles).  Highest priority lets them
+        // slip their few instructions in as soon as they are ready.
+        if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(3);
         const int lw = wave - NMW;
         int a_q[AIN]; int64_t a_pix[AIN]; uint32_t a_mask[AIN];
 #pragma unroll
@@ -325,37 +337,83 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
             b_ok[i] = n0 + row < p.Cout;
             b_row[i] = (int64_t)(n0 + row) * p.Cin;
         }
-        int it_t = 0, it_s = 0, it_c = 0, it_cg = 0, it_sbase = 0;
+        // The K loop walks "runs" = (tap, segment) pairs.  In-kernel stamps (PC_CONV_DBG=64, profiles/r01_tune_tune14.log)
+        // showed the loaders spending 1700-4700 cycles per chunk ISSUING 4-8 DMAs -- dependent scalar loads of the
+        // tap / segment tables from the kernel-argument segment plus 64-bit address arithmetic -- while the MFMA waves
+        // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS, every
+        // loader thread keeps running source pointers that just advance by BK per chunk, and only a run boundary
+        // (every nch/BK chunks) touches the descriptor table.
+        struct Run { const float* a_base; const float* w_base; int ld, nch, tap, pad; };
+        Run* runs = reinterpret_cast<Run*>(smem + 2 * STAGE);
+        const int nruns = T * p.nseg;
+        {
+            const int r = threadIdx.x - NMW * 64;
+            if (r < nruns) {
+                const int t = r / p.nseg, sg = r - t * p.nseg;
+                int cbase = 0;
+                for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
+                Run d;
+                d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
+                d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
+                d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
+                runs[r] = d;
+            }
+        }
+        __syncthreads();                                   // run table visible (MFMA waves execute the matching barrier)
+        const float* a_ptr[AIN]; bool a_ok[AIN];
+        const float* b_ptr[BIN];
+        int run = 0, c_left = 0;
+        auto enter_run = [&](int r) {
+            const Run d = runs[r];
+            c_left = d.nch;
+#pragma unroll
+            for (int i = 0; i < AIN; ++i) {
+                a_ptr[i] = d.a_base + a_pix[i] * d.ld + 4 * a_q[i];
+                a_ok[i] = (a_mask[i] >> d.tap) & 1u;
+            }
+#pragma unroll
+            for (int i = 0; i < BIN; ++i) b_ptr[i] = d.w_base + b_row[i] + 4 * b_q[i];
+        };
+        enter_run(0);
         auto issue = [&](int stage) {
-            const int dy = p.dy[phase][it_t], dx = p.dx[phase][it_t];
-            const int nch = p.seg[it_s].nch, sld = p.seg[it_s].ld;
-            const float* sp = (it_s == 0 ? seg0_ptr : p.seg[it_s].ptr) + (int64_t)(dy * p.W + dx) * sld + it_c;
-            const float* wp = wbase + (int64_t)p.wtap[phase][it_t] * p.Cout * p.Cin + it_cg;
             float4* lds_a = smem + stage * STAGE + lw * AIN * 64;
             float4* lds_b = smem + stage * STAGE + A_PIECES + lw * BIN * 64;
 #pragma unroll
             for (int i = 0; i < AIN; ++i) {
-                const bool ok = ((a_mask[i] >> it_t) & 1u) && (it_c + 4 * a_q[i] < nch);
-                const float* src = ok ? sp + a_pix[i] * sld + 4 * a_q[i] : pc_zero_page;
+                const float* src = (a_ok[i] && 4 * a_q[i] < c_left) ? a_ptr[i] : pc_zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16, 0, 0);
+                a_ptr[i] += BK;
             }
 #pragma unroll
             for (int i = 0; i < BIN; ++i) {
-                const bool ok = b_ok[i] && (it_c + 4 * b_q[i] < nch);
-                const float* src = ok ? wp + b_row[i] + 4 * b_q[i] : pc_zero_page;
+                const float* src = (b_ok[i] && 4 * b_q[i] < c_left) ? b_ptr[i] : pc_zero_page;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                                  (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16, 0, 0);
+                b_ptr[i] += BK;
             }
-            it_c += BK; it_cg += BK;
-            if (it_c >= nch) {
-                it_sbase += nch; it_c = 0; it_cg = it_sbase; ++it_s;
-                if (it_s >= p.nseg) { it_s = 0; it_sbase = 0; it_cg = 0; ++it_t; }
-            }
+            c_left -= BK;
+            if (c_left <= 0 && ++run < nruns) enter_run(run);
         };
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                   // stage 0 landed
+        if (p.dbg & 64) {                                  // diagnostic build: cycle stamps of the loader phases
+            unsigned long long s_issue = 0, s_dma = 0, s_bar = 0;
+            for (int c = 0; c < nchunks; ++c) {
+                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+                if (c + 1 < nchunks) issue((c + 1) & 1);
+                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+                __syncthreads();
+                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+                s_issue += t1 - t0; s_dma += t2 - t1; s_bar += t3 - t2;
+            }
+            const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+            if (wave == NMW && lane == 0 && blk < 8192) { pc_dbg_stamps[blk][0] = s_issue; pc_dbg_stamps[blk][1] = s_dma; pc_dbg_stamps[blk][2] = s_bar; pc_dbg_stamps[blk][3] = nchunks; }
+            return;
+        }
         for (int c = 0; c < nchunks; ++c) {
             if (c + 1 < nchunks && !(p.dbg & 2)) issue((c + 1) & 1);       // stage (c+1)&1 was last read in iteration c-1 (barrier passed)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -378,13 +436,13 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
         const float4* A = smem + stage * STAGE + am * KQ;
         const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
         constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
-        float4 va0[2][TM], va1[2][TM], vb[2];
+        float4 va[2][TM], vb[2];
+        // group g = 8 consecutive k = two 16-byte quads; lanes 0-31 take quad 2g, lanes 32-63 quad 2g+1, for A and B alike:
+        // MFMA step s then multiplies k = 8g+s (first) and k = 8g+4+s (second) -- the contract's in-group order
+        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand per 4 MFMAs and no VALU at all
         auto rd = [&](int g, int slot) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                va0[slot][i] = A[i * 32 * KQ + ((2 * g) ^ a_swz)];
-                va1[slot][i] = A[i * 32 * KQ + ((2 * g + 1) ^ a_swz)];
-            }
+            for (int i = 0; i < TM; ++i) va[slot][i] = A[i * 32 * KQ + ((2 * g + half) ^ a_swz)];
             vb[slot] = Bp[(2 * g + half) ^ b_swz];
         };
         rd(0, 0);
@@ -395,18 +453,34 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
             const float4 y = vb[g & 1];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const float4 x0 = va0[g & 1][i], x1 = va1[g & 1][i];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.y : x0.x, y.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x0.w : x0.z, y.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.y : x1.x, y.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(half ? x1.w : x1.z, y.w, acc[i], 0, 0, 0);
+                const float4 x = va[g & 1][i];
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[i], 0, 0, 0);
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[i], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     // an MFMA wave whose 32 columns all lie beyond Cout (N tails: 224, 176, 160, 96, 32 ...) only keeps the barriers
     const bool live = (n0 + wn * 32 < p.Cout) && !(p.dbg & 1);
+    __syncthreads();                                       // run table built by the loaders
     __syncthreads();                                       // stage 0 landed
+    if (p.dbg & 64) {                                      // diagnostic build: cycle stamps of the MFMA-wave phases
+        unsigned long long s_cmp = 0, s_bar = 0;
+        for (int c = 0; c < nchunks; ++c) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            if (live) compute(c & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+            __syncthreads();
+            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+            s_cmp += t1 - t0; s_bar += t2 - t1;
+        }
+        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        if (lane == 0 && blk < 8192) { pc_dbg_stamps[blk][4 + (wave & 1) * 2] = s_cmp; pc_dbg_stamps[blk][5 + (wave & 1) * 2] = s_bar; }
+    } else
     for (int c = 0; c < nchunks; ++c) {
         if (live) compute(c & 1);
         __syncthreads();
@@ -451,6 +525,12 @@ hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
 }
 
 }  // namespace
+
+extern "C" __attribute__((visibility("default"))) int pc_debug_read_stamps(unsigned long long* dst, int nblocks)
+{
+    if (!dst || nblocks <= 0 || nblocks > 8192) return PC_ERR_ARG;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pc_dbg_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? PC_OK : PC_ERR_HIP;
+}
 
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
 {

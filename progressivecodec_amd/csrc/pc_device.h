@@ -45,7 +45,7 @@ struct pc_conv_params {
     int8_t dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
     int wtap[4][PC_MAX_TAP];                 // weight tap index
     int stride;
-    // weights: layout 0 = [ntaps][Cin][Cout]; layout 1 = [ntaps][Cout][Cin], k permuted in groups of 8 (pc_conv.hip)
+    // weights: layout 0 = [ntaps][Cin][Cout]; layout 1 = [ntaps][Cout][Cin] (pc_conv.hip)
     const float* w;
     int wlayout;
     const float* bias;

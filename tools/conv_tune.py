@@ -59,6 +59,15 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / n
             print(f"{name:10s} M={B*Ho*Wo:7d} N={co:4d} K={k*k*ci:5d} cfg {cfg}: {us:9.1f} us  {flops/us/1e6:6.1f} TFLOP/s", flush=True)
+            if int(os.environ.get("PC_CONV_DBG", "0")) & 64:
+                nb = min(8192, ((B * Ho * Wo + 63) // 64) * ((co + 63) // 64))
+                st = np.zeros((nb, 8), np.uint64)
+                check(L.pc_debug_read_stamps(st.ctypes.data_as(C.c_void_p), nb))
+                st = st.astype(np.float64)
+                n = st[:, 3].mean()
+                print(f"   per chunk (cycles, mean over {nb} blocks, {n:.0f} chunks): loader issue {st[:,0].mean()/n:7.0f}  dma wait {st[:,1].mean()/n:7.0f}  "
+                      f"loader barrier wait {st[:,2].mean()/n:7.0f} | mfma wave0 compute {st[:,4].mean()/n:7.0f} barrier wait {st[:,5].mean()/n:7.0f} | "
+                      f"wave1 compute {st[:,6].mean()/n:7.0f} barrier wait {st[:,7].mean()/n:7.0f}", flush=True)
 
 
 if __name__ == "__main__":
