@@ -277,11 +277,11 @@ __device__ unsigned long long pc_dbg_stamps[8192][8];
 
 template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
 
-template <int BK, int BN, int TM>
-__global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(const pc_conv_params p)
+template <int BK, int TM, int TN>
+__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_params p)
 {
-    constexpr int BM = 64 * TM, KQ = BK / 4;             // each MFMA wave owns TM row-tiles of 32x32
-    constexpr int NMW = 2 * (BN / 32);                    // MFMA waves (2 x BN/32 tiles of 32x32); as many loader waves
+    constexpr int BM = 64 * TM, BN = 64 * TN, KQ = BK / 4;   // 2x2 MFMA waves, each owning TM x TN tiles of 32x32
+    constexpr int NMW = 4;                                // MFMA waves; as many loader waves
     constexpr int NLT = NMW * 64;                         // loader threads
     constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
     constexpr int AIN = A_PIECES / NLT, BIN = B_PIECES / NLT;       // DMA instructions per loader thread per chunk
@@ -423,47 +423,55 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
     }
 
     // ---------------------------------------------------------------------- MFMA waves
-    const int wm = BN == 64 ? (wave >> 1) : wave, wn = BN == 64 ? (wave & 1) : 0;
+    const int wm = wave >> 1, wn = wave & 1;
     const int half = lane >> 5, l31 = lane & 31;
-    const int am = wm * (32 * TM) + l31, bn = wn * 32 + l31;   // this lane's first A row / B row inside the block tile
-    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);  // (32-row steps keep the swizzle of a lane unchanged)
-    f32x16 acc[TM];
+    const int am = wm * (32 * TM) + l31, bn = wn * (32 * TN) + l31;   // this lane's first A row / B row inside the block tile
+    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);         // (32-row steps keep the swizzle of a lane unchanged)
+    // column tiles of this wave that lie inside Cout (N tails: 224, 176, 160, 96, 32 ...); dead tiles issue no MFMAs
+    bool live_j[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) live_j[j] = (n0 + wn * (32 * TN) + j * 32 < p.Cout) && !(p.dbg & 1);
+    const bool live = live_j[0];
+    f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     auto compute = [&](int stage) {
         const float4* A = smem + stage * STAGE + am * KQ;
         const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
         constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
-        float4 va[2][TM], vb[2];
+        float4 va[2][TM], vb[2][TN];
         // group g = 8 consecutive k = two 16-byte quads; lanes 0-31 take quad 2g, lanes 32-63 quad 2g+1, for A and B alike:
         // MFMA step s then multiplies k = 8g+s (first) and k = 8g+4+s (second) -- the contract's in-group order
-        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand per 4 MFMAs and no VALU at all
+        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand tile per 4 MFMAs and no VALU at all
         auto rd = [&](int g, int slot) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) va[slot][i] = A[i * 32 * KQ + ((2 * g + half) ^ a_swz)];
-            vb[slot] = Bp[(2 * g + half) ^ b_swz];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) vb[slot][j] = Bp[j * 32 * KQ + ((2 * g + half) ^ b_swz)];
         };
         rd(0, 0);
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            const float4 y = vb[g & 1];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const float4 x = va[g & 1][i];
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[i], 0, 0, 0);
-                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[i], 0, 0, 0);
-            }
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if (!live_j[j]) continue;
+                    const float4 x = va[g & 1][i], y = vb[g & 1][j];
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[i][j], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // an MFMA wave whose 32 columns all lie beyond Cout (N tails: 224, 176, 160, 96, 32 ...) only keeps the barriers
-    const bool live = (n0 + wn * 32 < p.Cout) && !(p.dbg & 1);
     __syncthreads();                                       // run table built by the loaders
     __syncthreads();                                       // stage 0 landed
     if (p.dbg & 64) {                                      // diagnostic build: cycle stamps of the MFMA-wave phases
@@ -488,6 +496,8 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
     if (!live) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m0 + wm * (32 * TM) + i * 32 + row;
@@ -495,9 +505,9 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
         const int b = m / HoWo, rr = m - b * HoWo;
         const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
         const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-        const int n = n0 + wn * 32 + l31;
+        const int n = n0 + wn * (32 * TN) + j * 32 + l31;
         if (n >= p.Cout) continue;
-        float v = acc[i][r];
+        float v = acc[i][j][r];
         if (bias) v = v + bias[n];
         int nn = n, YY = Y, XX = X;
         if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
@@ -507,12 +517,12 @@ __global__ __launch_bounds__(BN == 64 ? 512 : 256) void conv_igemm_dma_kernel(co
     }
 }
 
-template <int BK, int BN, int TM>
+template <int BK, int TM, int TN>
 hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
-    constexpr int BM = 64 * TM;
+    constexpr int BM = 64 * TM, BN = 64 * TN;
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ngroup == 2 ? 2 : p.nphase);
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK, BN, TM>), grid, dim3(BN == 64 ? 512 : 256), 0, stream, p);
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK, TM, TN>), grid, dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -571,10 +581,11 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         for (int ph = 0; ph < p.nphase; ++ph) ktot = std::max<long>(ktot, (long)p.ntap[ph] * p.Cin);
         const long blocks = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
         static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
-        // variants measured and rejected (tools/conv_tune.py, profiles/r01_tune_*.log): 64x32 and 128x64 block tiles,
-        // register-staged loaders (plain, prefetch distance 2, and with the even/odd k split done by the loader)
+        // Wave tiles of 2x1 / 1x2 / 2x2 MFMA tiles (128x64, 64x128, 128x128 blocks) are supported by the template and were
+        // measured (profiles/r01_tune_tune17.log): no gain on large grids (93.6 / 95.4 / 87.2 / 89.5 TFLOP/s), slower on the
+        // slice-chain GEMMs -- only the 64x64 form is instantiated.
         const int bk = bk_env ? bk_env : ((blocks < 1024 && ktot >= 1024) ? 64 : 32);
-        e = bk == 64 ? launch_dma<64, 64, 1>(p, stream) : launch_dma<32, 64, 1>(p, stream);
+        e = bk == 64 ? launch_dma<64, 1, 1>(p, stream) : launch_dma<32, 1, 1>(p, stream);
     } else {
         if (p.ngroup == 2) return PC_ERR_ARG;
         int cfg = p.tile_cfg;

@@ -147,3 +147,41 @@ def test_compress_with_ac_harness_rd_table():
             assert abs(rows[k]["psnr"] - psnr_of(x, xh)) < 1e-5
             k += 1
     assert bpp == sorted(bpp)
+
+
+def test_config1_shape_bit_exact_vs_oracle():
+    """BASELINE.json Config 1 shape (one 512x768 image, one mask level): every byte string and x_hat equal the oracle's."""
+    x = inputs(1, 512, 768, 100, "smooth")
+    net = gpu_codec()
+    q = 0.5
+    out = net.compress(x.cuda(), q, "point-based-std")
+    orc = oracle_codec("cdet")
+    ref = orc.compress(x, q)
+    assert out["strings"][1] == ref["strings"][1]
+    assert out["strings"][0] == ref["strings"][0]
+    assert tuple(out["shape"]) == (8, 12)
+    dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")["x_hat"].cpu()
+    rdec = orc.decompress(ref["strings"], ref["shape"], q)["x_hat"]
+    assert np.array_equal(dec.numpy().view(np.uint32), rdec.numpy().view(np.uint32))
+
+
+def test_large_tiles_round_trip_properties():
+    """Config 4 tile size (1024x1024), 2 images: size-independent properties -- the decoder reproduces exactly the
+    reconstruction implied by the encoder's own symbols for every image independently (image 1 alone == image 1 in the
+    batch), byte counts are plausible, x_hat is inside [0,1]."""
+    net = gpu_codec()
+    x = inputs(2, 1024, 1024, 77).cuda()
+    q = 2
+    out = net.compress(x, q, "point-based-std")
+    one = net.compress(x[1:2].contiguous(), q, "point-based-std")
+    assert [sl[1] for sl in out["strings"][0]] == [sl[0] for sl in one["strings"][0]]
+    dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")["x_hat"]
+    dec1 = net.decompress(one["strings"], one["shape"], q, "point-based-std")["x_hat"]
+    assert torch.equal(dec[1], dec1[0])
+    assert 0.0 <= dec.min().item() and dec.max().item() <= 1.0
+    k = 32 * 64 * 64
+    for m in out["masks"]:
+        s = m.sum(dim=(1, 2, 3)).cpu()
+        assert ((s - 0.2 * k).abs() <= 4).all(), s
+    bpp = bpp_of(out["strings"], 2, 1024, 1024)
+    assert 1.0 < bpp < 10.0
