@@ -105,8 +105,9 @@ def _nchw(a):
 
 
 class CDetOps:
-    """Numeric-contract primitives (oracle/pc_oracle.c).  Chain order: taps in (ky, kx)
-    ascending, then input channel ascending; bias added after the chain."""
+    """Numeric-contract primitives (oracle/pc_oracle.c).  Chain order: flattened k = tap * Cin + channel
+    (taps in (ky, kx) ascending), aligned groups of 8 visited 0,4,1,5,2,6,3,7 inside a group (DESIGN.md section 2);
+    bias added after the chain."""
     name = "cdet"
 
     def conv(self, x, w, b, stride, pad):
