@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "../../include/pc_math.h"
@@ -270,24 +271,52 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // group's first 16-byte quad and lanes 32-63 its second: per 4 MFMAs an MFMA wave issues 2
 // ds_read_b128 and no VALU (an earlier k-ascending contract needed 3 reads + 4 v_cndmask per 4 MFMAs:
 // 22 % slower, PC_CONV_DBG ablation in profiles/r01_tune_tune12.log).
+//
+// Template: K-chunk BK, S LDS stages (the loaders keep S-1 chunks in flight behind counted
+// `s_waitcnt vmcnt(N)`; raw `s_barrier`s, which do not drain VMEM, hand a landed stage to the MFMA waves),
+// WM x WN MFMA waves of one 32x32 tile each (block tile 32*WM x 32*WN) and as many loader waves.
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) float pc_zero_page[16];
 // diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop phases, [block][8]
-__device__ unsigned long long pc_dbg_stamps[8192][8];
+__device__ unsigned long long pc_dbg_stamps[8192][12];
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
 
-template <int BK, int TM, int TN>
-__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_params p)
+template <int N> __device__ __forceinline__ void pc_wait_vm()
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN, KQ = BK / 4;   // 2x2 MFMA waves, each owning TM x TN tiles of 32x32
-    constexpr int NMW = 4;                                // MFMA waves; as many loader waves
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// wait until at most `chunks` * NI of this wave's DMA instructions are still in flight (chunks is wave-uniform, small)
+template <int NI, int MAXC> __device__ __forceinline__ void pc_wait_chunks(int chunks)
+{
+    if constexpr (MAXC <= 0) pc_wait_vm<0>();
+    else {
+        if (chunks >= MAXC) pc_wait_vm<MAXC * NI>();
+        else pc_wait_chunks<NI, MAXC - 1>(chunks);
+    }
+}
+
+struct pc_run { const float* a_base; const float* w_base; int ld, nch, tap, pad; };   // one (tap, input segment) of the K loop
+
+template <int BK, int S, int WM, int WN, bool STAMPS>
+__global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_conv_params p)
+{
+    constexpr int BM = 32 * WM, BN = 32 * WN, KQ = BK / 4;
+    constexpr int NMW = WM * WN;                          // MFMA waves; as many loader waves
     constexpr int NLT = NMW * 64;                         // loader threads
     constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
     constexpr int AIN = A_PIECES / NLT, BIN = B_PIECES / NLT;       // DMA instructions per loader thread per chunk
-    __shared__ float4 smem[2 * STAGE + PC_MAX_TAP * PC_MAX_SEG * 2];   // two stages + the (tap, segment) run table
+    constexpr int NI = AIN + BIN;
+    static_assert(AIN >= 1 && BIN >= 1 && A_PIECES % NLT == 0 && B_PIECES % NLT == 0, "tile / loader mismatch");
+    static_assert((S - 2) * NI < 64, "vmcnt range");
+    extern __shared__ float4 smem[];                      // S stages, then the run table (launch_dma sizes it)
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long t_entry = 0;
+    if (STAMPS) t_entry = __builtin_amdgcn_s_memtime();
     int phase = blockIdx.z;
     const float* seg0_ptr = p.seg[0].ptr;
     const float* wbase = p.w;
@@ -300,13 +329,14 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
     int chunks_per_tap = 0;
     for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
     const int nchunks = T * chunks_per_tap;
+    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
 
     if (wave >= NMW) {
         // ------------------------------------------------------------------ loader waves
         // The loaders issue ~30 instructions per chunk; at default priority they only got an issue slot about once per
         // MFMA of their SIMD partner (stamps: loader issue time == MFMA phase + 200 cycles).  Highest priority lets them
         // slip their few instructions in as soon as they are ready.
-        if (!(p.dbg & 128)) __builtin_amdgcn_s_setprio(3);
+        __builtin_amdgcn_s_setprio(3);
         const int lw = wave - NMW;
         int a_q[AIN]; int64_t a_pix[AIN]; uint32_t a_mask[AIN];
 #pragma unroll
@@ -326,7 +356,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
                 const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
                 if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
             }
-            a_mask[i] = mask;
+            a_mask[i] = (p.dbg & 4) ? 0u : mask;          // ablation 4: every DMA reads the zero page (no L2 traffic, same instruction stream)
         }
         int b_q[BIN]; int64_t b_row[BIN]; bool b_ok[BIN];
 #pragma unroll
@@ -334,7 +364,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
             const int pb = (lw * BIN + i) * 64 + lane;
             const int row = pb / KQ, slot = pb % KQ;
             b_q[i] = slot ^ pc_swz<KQ>(row);
-            b_ok[i] = n0 + row < p.Cout;
+            b_ok[i] = n0 + row < p.Cout && !(p.dbg & 4);
             b_row[i] = (int64_t)(n0 + row) * p.Cin;
         }
         // The K loop walks "runs" = (tap, segment) pairs.  In-kernel stamps (PC_CONV_DBG=64, profiles/r01_tune_tune14.log)
@@ -343,36 +373,41 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
         // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS, every
         // loader thread keeps running source pointers that just advance by BK per chunk, and only a run boundary
         // (every nch/BK chunks) touches the descriptor table.
-        struct Run { const float* a_base; const float* w_base; int ld, nch, tap, pad; };
-        Run* runs = reinterpret_cast<Run*>(smem + 2 * STAGE);
+        pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
         const int nruns = T * p.nseg;
-        {
-            const int r = threadIdx.x - NMW * 64;
-            if (r < nruns) {
-                const int t = r / p.nseg, sg = r - t * p.nseg;
-                int cbase = 0;
-                for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
-                Run d;
-                d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
-                d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
-                d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
-                runs[r] = d;
-            }
+        for (int r = threadIdx.x - NLT; r < nruns; r += NLT) {
+            const int t = r / p.nseg, sg = r - t * p.nseg;
+            int cbase = 0;
+            for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
+            pc_run d;
+            d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
+            d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
+            d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
+            runs[r] = d;
         }
         __syncthreads();                                   // run table visible (MFMA waves execute the matching barrier)
+        const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
         const float* a_ptr[AIN]; bool a_ok[AIN];
         const float* b_ptr[BIN];
         int run = 0, c_left = 0;
         auto enter_run = [&](int r) {
-            const Run d = runs[r];
-            c_left = d.nch;
+            // The descriptor is read with hand-written ds_read_b128: behind a plain LDS load hipcc places `s_waitcnt vmcnt(0)`
+            // (it must assume the read aliases an in-flight LDS-DMA), which would drain the prefetch pipeline at every run
+            // boundary.  The table is written once, before the first DMA, and no DMA targets it.
+            u32x4 lo, hi;
+            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(lo), "=&v"(hi) : "v"(runs_lds + (uint32_t)r * 32u) : "memory");
+            const float* d_a = reinterpret_cast<const float*>(((uint64_t)lo.y << 32) | lo.x);
+            const float* d_w = reinterpret_cast<const float*>(((uint64_t)lo.w << 32) | lo.z);
+            const int d_ld = (int)hi.x, d_nch = (int)hi.y, d_tap = (int)hi.z;
+            c_left = d_nch;
 #pragma unroll
             for (int i = 0; i < AIN; ++i) {
-                a_ptr[i] = d.a_base + a_pix[i] * d.ld + 4 * a_q[i];
-                a_ok[i] = (a_mask[i] >> d.tap) & 1u;
+                a_ptr[i] = d_a + a_pix[i] * d_ld + 4 * a_q[i];
+                a_ok[i] = (a_mask[i] >> d_tap) & 1u;
             }
 #pragma unroll
-            for (int i = 0; i < BIN; ++i) b_ptr[i] = d.w_base + b_row[i] + 4 * b_q[i];
+            for (int i = 0; i < BIN; ++i) b_ptr[i] = d_w + b_row[i] + 4 * b_q[i];
         };
         enter_run(0);
         auto issue = [&](int stage) {
@@ -395,134 +430,137 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const pc_conv_param
             c_left -= BK;
             if (c_left <= 0 && ++run < nruns) enter_run(run);
         };
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                   // stage 0 landed
-        if (p.dbg & 64) {                                  // diagnostic build: cycle stamps of the loader phases
-            unsigned long long s_issue = 0, s_dma = 0, s_bar = 0;
-            for (int c = 0; c < nchunks; ++c) {
-                const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-                if (c + 1 < nchunks) issue((c + 1) & 1);
-                const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-                __syncthreads();
-                const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-                s_issue += t1 - t0; s_dma += t2 - t1; s_bar += t3 - t2;
-            }
-            const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-            if (wave == NMW && lane == 0 && blk < 8192) { pc_dbg_stamps[blk][0] = s_issue; pc_dbg_stamps[blk][1] = s_dma; pc_dbg_stamps[blk][2] = s_bar; pc_dbg_stamps[blk][3] = nchunks; }
-            return;
-        }
+        // chunk c lives in stage c % S; chunks c+1 .. c+S-1 are in flight while the MFMA waves work on chunk c
+        int issued = 0, st_issue = 0;
+        for (; issued < S - 1 && issued < nchunks; ++issued) { issue(st_issue); st_issue = st_issue + 1 == S ? 0 : st_issue + 1; }
+        pc_wait_chunks<NI, S - 2>(issued - 1);             // chunk 0 landed
+        __builtin_amdgcn_s_barrier();
+        unsigned long long s_issue = 0, s_dma = 0, s_bar = 0;
         for (int c = 0; c < nchunks; ++c) {
-            if (c + 1 < nchunks && !(p.dbg & 2)) issue((c + 1) & 1);       // stage (c+1)&1 was last read in iteration c-1 (barrier passed)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            unsigned long long t0 = 0, t1 = 0, t2 = 0;
+            if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+            // stage (c+S-1) % S was last read while computing chunk c-1: the barrier that ended iteration c-1 released it
+            if (issued < nchunks && !(p.dbg & 2)) { issue(st_issue); st_issue = st_issue + 1 == S ? 0 : st_issue + 1; ++issued; }
+            if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
+            pc_wait_chunks<NI, S - 2>(issued - (c + 2));   // chunk c+1 landed (those after it may still be in flight)
+            if (STAMPS) t2 = __builtin_amdgcn_s_memtime();
+            __builtin_amdgcn_s_barrier();
+            if (STAMPS) { s_issue += t1 - t0; s_dma += t2 - t1; s_bar += __builtin_amdgcn_s_memtime() - t2; }
+        }
+        if (STAMPS && wave == NMW && lane == 0 && blk < 8192) {
+            pc_dbg_stamps[blk][0] = s_issue; pc_dbg_stamps[blk][1] = s_dma; pc_dbg_stamps[blk][2] = s_bar; pc_dbg_stamps[blk][3] = nchunks;
         }
         return;
     }
 
     // ---------------------------------------------------------------------- MFMA waves
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
-    const int am = wm * (32 * TM) + l31, bn = wn * (32 * TN) + l31;   // this lane's first A row / B row inside the block tile
-    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);         // (32-row steps keep the swizzle of a lane unchanged)
-    // column tiles of this wave that lie inside Cout (N tails: 224, 176, 160, 96, 32 ...); dead tiles issue no MFMAs
-    bool live_j[TN];
+    const int am = wm * 32 + l31, bn = wn * 32 + l31;      // this lane's A row / B row inside the block tile
+    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);
+    // column tiles that lie outside Cout (N tails: 224, 176, 160, 96, 32 ...) issue no MFMAs
+    const bool live = (n0 + wn * 32 < p.Cout) && !(p.dbg & 1);
+    f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) live_j[j] = (n0 + wn * (32 * TN) + j * 32 < p.Cout) && !(p.dbg & 1);
-    const bool live = live_j[0];
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
     auto compute = [&](int stage) {
         const float4* A = smem + stage * STAGE + am * KQ;
         const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
         constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
-        float4 va[2][TM], vb[2][TN];
+        float4 va[2], vb[2];
         // group g = 8 consecutive k = two 16-byte quads; lanes 0-31 take quad 2g, lanes 32-63 quad 2g+1, for A and B alike:
         // MFMA step s then multiplies k = 8g+s (first) and k = 8g+4+s (second) -- the contract's in-group order
-        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand tile per 4 MFMAs and no VALU at all
-        auto rd = [&](int g, int slot) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) va[slot][i] = A[i * 32 * KQ + ((2 * g + half) ^ a_swz)];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) vb[slot][j] = Bp[j * 32 * KQ + ((2 * g + half) ^ b_swz)];
-        };
-        rd(0, 0);
+        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand per 4 MFMAs and no VALU at all
+        va[0] = A[(half) ^ a_swz]; vb[0] = Bp[(half) ^ b_swz];
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) rd(g + 1, (g + 1) & 1);
+            if (g + 1 < NG) { va[(g + 1) & 1] = A[(2 * (g + 1) + half) ^ a_swz]; vb[(g + 1) & 1] = Bp[(2 * (g + 1) + half) ^ b_swz]; }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (!live_j[j]) continue;
-                    const float4 x = va[g & 1][i], y = vb[g & 1][j];
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc[i][j], 0, 0, 0);
-                }
+            const float4 x = va[g & 1], y = vb[g & 1];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc, 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
     __syncthreads();                                       // run table built by the loaders
-    __syncthreads();                                       // stage 0 landed
-    if (p.dbg & 64) {                                      // diagnostic build: cycle stamps of the MFMA-wave phases
-        unsigned long long s_cmp = 0, s_bar = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            if (live) compute(c & 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-            __syncthreads();
-            const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-            s_cmp += t1 - t0; s_bar += t2 - t1;
-        }
-        const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        if (lane == 0 && blk < 8192) { pc_dbg_stamps[blk][4 + (wave & 1) * 2] = s_cmp; pc_dbg_stamps[blk][5 + (wave & 1) * 2] = s_bar; }
-    } else
+    __builtin_amdgcn_s_barrier();                          // chunk 0 landed
+    unsigned long long s_cmp = 0, s_bar = 0, t_loop = 0, t_epi = 0, r_loop = 0, r_epi = 0;
+    if (STAMPS) { t_loop = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
+    int st = 0;
     for (int c = 0; c < nchunks; ++c) {
-        if (live) compute(c & 1);
-        __syncthreads();
+        unsigned long long t0 = 0, t1 = 0;
+        if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
+        if (live) compute(st);
+        st = st + 1 == S ? 0 : st + 1;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are complete before it is released
+        if (STAMPS) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); }
+        __builtin_amdgcn_s_barrier();
+        if (STAMPS) { s_cmp += t1 - t0; s_bar += __builtin_amdgcn_s_memtime() - t1; }
     }
+    if (STAMPS && lane == 0 && blk < 8192) { pc_dbg_stamps[blk][4 + (wave & 1) * 2] = s_cmp; pc_dbg_stamps[blk][5 + (wave & 1) * 2] = s_bar; }
+    if (STAMPS) { t_epi = __builtin_amdgcn_s_memtime(); r_epi = __builtin_amdgcn_s_memrealtime(); }
     if (!live) return;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
+    const int n = n0 + wn * 32 + l31;
+    if (n >= p.Cout) return;
+    const float bv = bias ? bias[n] : 0.0f;
+    if (p.dense_out) {
+        // stride-1 layers storing a plain NHWC(-strided) tensor: the output pixel index is the GEMM row, no div/mod
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= p.M) continue;
+            float v = acc[r];
+            if (bias) v = v + bv;
+            v = epilogue_value(p, v, (int64_t)m, n);
+            outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = v;
+        }
+    } else
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = m0 + wm * (32 * TM) + i * 32 + row;
+        const int m = m0 + wm * 32 + row;
         if (m >= p.M) continue;
         const int b = m / HoWo, rr = m - b * HoWo;
         const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
         const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-        const int n = n0 + wn * (32 * TN) + j * 32 + l31;
-        if (n >= p.Cout) continue;
-        float v = acc[i][j][r];
-        if (bias) v = v + bias[n];
+        float v = acc[r];
+        if (bias) v = v + bv;
         int nn = n, YY = Y, XX = X;
         if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
         const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
         v = epilogue_value(p, v, pix, nn);
         outp[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
     }
+    if (STAMPS && wave == 0 && lane == 0 && blk < 8192) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        pc_dbg_stamps[blk][8] = t_loop - t_entry; pc_dbg_stamps[blk][9] = __builtin_amdgcn_s_memtime() - t_epi;
+        pc_dbg_stamps[blk][10] = t_epi - t_loop; pc_dbg_stamps[blk][11] = r_epi - r_loop;   // in-kernel clock = [10]/[11] x 100 MHz
+    }
 }
 
-template <int BK, int TM, int TN>
+template <int BK, int S, int WM, int WN>
 hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
+    constexpr int BM = 32 * WM, BN = 32 * WN;
+    int tmax = 0;
+    for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
+    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ngroup == 2 ? 2 : p.nphase);
-    hipLaunchKernelGGL((conv_igemm_dma_kernel<BK, TM, TN>), grid, dim3(512), 0, stream, p);
+    const bool stamps = (p.dbg & 64) != 0;
+    auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true> : conv_igemm_dma_kernel<BK, S, WM, WN, false>;
+    static bool attr_set[2] = {false, false};             // per instantiation: allow more than 64 KB of dynamic LDS
+    if (lds > 48 * 1024 && !attr_set[stamps]) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+            return hipGetLastError();
+        attr_set[stamps] = true;
+    }
+    if (p.dbg & 256) {
+        int nb = -1;
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 128 * WM * WN, lds);
+        fprintf(stderr, "[pc_conv] dma<%d,%d,%d,%d> grid %u x %u x %u, lds %zu B, max active blocks per CU %d\n", BK, S, WM, WN, grid.x, grid.y,
+                grid.z, lds, nb);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(128 * WM * WN), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -539,7 +577,7 @@ hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
 extern "C" __attribute__((visibility("default"))) int pc_debug_read_stamps(unsigned long long* dst, int nblocks)
 {
     if (!dst || nblocks <= 0 || nblocks > 8192) return PC_ERR_ARG;
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pc_dbg_stamps), sizeof(unsigned long long) * 8 * (size_t)nblocks) == hipSuccess ? PC_OK : PC_ERR_HIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pc_dbg_stamps), sizeof(unsigned long long) * 12 * (size_t)nblocks) == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
@@ -554,6 +592,9 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
     if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
     static const int dbg_env = [] { const char* v = std::getenv("PC_CONV_DBG"); return v ? std::atoi(v) : 0; }();
     if (dbg_env) const_cast<pc_conv_params&>(p).dbg = dbg_env;
+    const_cast<pc_conv_params&>(p).dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&
+                                               p.outW == p.Wo && !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx &&
+                                               p.out_sb == (int64_t)p.outH * p.out_sy;
     if (!p.smallc) {
         int c = 0;
         if (p.nseg < 1 || p.nseg > PC_MAX_SEG) return PC_ERR_ARG;
@@ -570,22 +611,26 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
 
     // Kernel selection (measured on MI355X with tools/conv_tune.py; profiles/r01_*):
     //  * weight layout 1 (chosen at pack time by pc_conv_weight_layout: K per phase > 256, Cout > 4, Cin % 16 == 0):
-    //    wave-specialised 64x64 LDS-DMA kernel; K-chunk 64 when the grid is small (slice-chain GEMMs), else 32;
+    //    wave-specialised 64x64 LDS-DMA kernel, K-chunk 32, three LDS stages;
     //  * weight layout 0: the plain BK=16 kernel (1x1 convs / GDN: epilogue-dominated; the 3-channel output layer;
     //    the 3-channel input layer through the element-gather loader).
     hipError_t e;
     if (p.wlayout == 1) {
         if (p.smallc || p.square || (p.Cin % 16)) return PC_ERR_ARG;
         if (p.ngroup == 2 && (p.nphase != 1 || !p.g1_seg0 || !p.g1_w || !p.g1_out)) return PC_ERR_ARG;
-        long ktot = 0;
-        for (int ph = 0; ph < p.nphase; ++ph) ktot = std::max<long>(ktot, (long)p.ntap[ph] * p.Cin);
-        const long blocks = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
+        // Measured on MI355X (tools/conv_tune.py; profiles/r01_tune_tune18.log, tune25, tune26): K-chunk 32 with three LDS stages
+        // (two chunks in flight) wins or ties on every layer shape of the codec, small and large grids alike -- 64-channel
+        // chunks, 2 or 4 stages and the 32x64 / 64x32 / 32x32 block tiles (WM, WN < 2) were all slower or equal.  The other
+        // instantiations stay reachable for tuning through PC_CONV_BK / PC_CONV_S.
         static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
-        // Wave tiles of 2x1 / 1x2 / 2x2 MFMA tiles (128x64, 64x128, 128x128 blocks) are supported by the template and were
-        // measured (profiles/r01_tune_tune17.log): no gain on large grids (93.6 / 95.4 / 87.2 / 89.5 TFLOP/s), slower on the
-        // slice-chain GEMMs -- only the 64x64 form is instantiated.
-        const int bk = bk_env ? bk_env : ((blocks < 1024 && ktot >= 1024) ? 64 : 32);
-        e = bk == 64 ? launch_dma<64, 1, 1>(p, stream) : launch_dma<32, 1, 1>(p, stream);
+        static const int s_env = [] { const char* v = std::getenv("PC_CONV_S"); return v ? std::atoi(v) : 0; }();
+        const int bk = bk_env ? bk_env : 32;
+        const int S = s_env ? s_env : 3;
+        e = hipErrorInvalidValue;
+#define PC_DMA_CASE(BK_, S_) if (bk == BK_ && S == S_) e = launch_dma<BK_, S_, 2, 2>(p, stream);
+        PC_DMA_CASE(32, 3) PC_DMA_CASE(32, 2) PC_DMA_CASE(32, 4) PC_DMA_CASE(64, 2) PC_DMA_CASE(64, 3)
+#undef PC_DMA_CASE
+        if (e == hipErrorInvalidValue) return PC_ERR_ARG;
     } else {
         if (p.ngroup == 2) return PC_ERR_ARG;
         int cfg = p.tile_cfg;

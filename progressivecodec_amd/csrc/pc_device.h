@@ -42,7 +42,7 @@ struct pc_conv_params {
     // taps per output phase
     int nphase;
     int ntap[4];
-    int8_t dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
+    int dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];   // int32: wave-uniform reads become s_load_dword (int8 made hipcc emit vector byte loads)
     int wtap[4][PC_MAX_TAP];                 // weight tap index
     int stride;
     // weights: layout 0 = [ntaps][Cin][Cout]; layout 1 = [ntaps][Cout][Cin] (pc_conv.hip)
@@ -66,6 +66,7 @@ struct pc_conv_params {
     // it differs only in its first input segment, weights, bias and output
     int ngroup;
     const float* g1_seg0; const float* g1_w; const float* g1_bias; float* g1_out;
+    int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
     int dbg;                                 // tuning ablations only (PC_CONV_DBG): 1 = skip MFMA, 2 = skip loader work
 };
 

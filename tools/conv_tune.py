@@ -18,6 +18,12 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
     ("stack_L3", 32, 16, 16, 176, 128, 3, 1),
     ("stack_L4", 32, 16, 16, 128, 64, 3, 1),
     ("stack_L5", 32, 16, 16, 64, 32, 3, 1),
+    # the codec launches cc_mean || cc_scale as one grouped launch: same block count as a batch of 64
+    ("stackg_L1", 64, 16, 16, 512, 224, 3, 1),
+    ("stackg_L2", 64, 16, 16, 224, 176, 3, 1),
+    ("stackg_L3", 64, 16, 16, 176, 128, 3, 1),
+    ("stackg_L4", 64, 16, 16, 128, 64, 3, 1),
+    ("stackg_L5", 64, 16, 16, 64, 32, 3, 1),
     ("ga_conv2", 32, 128, 128, 192, 192, 5, 2),
     ("ru_3x3", 32, 64, 64, 96, 96, 3, 1),
     ("ru_1x1", 32, 64, 64, 96, 192, 1, 1),
@@ -51,7 +57,7 @@ def main():
                 continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            n = 20
+            n = int(os.environ.get("PC_TUNE_ITERS", "20"))
             e0.record()
             for _ in range(n):
                 run()
@@ -61,13 +67,16 @@ def main():
             print(f"{name:10s} M={B*Ho*Wo:7d} N={co:4d} K={k*k*ci:5d} cfg {cfg}: {us:9.1f} us  {flops/us/1e6:6.1f} TFLOP/s", flush=True)
             if int(os.environ.get("PC_CONV_DBG", "0")) & 64:
                 nb = min(8192, ((B * Ho * Wo + 63) // 64) * ((co + 63) // 64))
-                st = np.zeros((nb, 8), np.uint64)
+                st = np.zeros((nb, 12), np.uint64)
                 check(L.pc_debug_read_stamps(st.ctypes.data_as(C.c_void_p), nb))
                 st = st.astype(np.float64)
                 n = st[:, 3].mean()
                 print(f"   per chunk (cycles, mean over {nb} blocks, {n:.0f} chunks): loader issue {st[:,0].mean()/n:7.0f}  dma wait {st[:,1].mean()/n:7.0f}  "
                       f"loader barrier wait {st[:,2].mean()/n:7.0f} | mfma wave0 compute {st[:,4].mean()/n:7.0f} barrier wait {st[:,5].mean()/n:7.0f} | "
                       f"wave1 compute {st[:,6].mean()/n:7.0f} barrier wait {st[:,7].mean()/n:7.0f}", flush=True)
+                print(f"   per block (cycles): prologue {st[:,8].mean():7.0f}  K loop {(st[:,4]+st[:,5]).mean():8.0f}  epilogue {st[:,9].mean():7.0f}  "
+                      f"| in-kernel clock over the K loop (s_memtime / s_memrealtime x 100 MHz, median over blocks) "
+                      f"{np.median(st[:,10] / np.maximum(st[:,11], 1)) * 0.1:5.2f} GHz", flush=True)
 
 
 if __name__ == "__main__":
