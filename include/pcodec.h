@@ -97,8 +97,8 @@ PC_API int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin,
                           const float* w_packed, const float* bias, int kind, int Cout, int k, int stride,
                           int act, int tile_cfg, float* out, void* stream);
 
-/* GDN / IGDN (layers/gdn.py:50-63) with already re-parametrised beta [C], gamma_t [C_in][C_out] = gamma^T. */
-PC_API int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma_t,
+/* GDN / IGDN (layers/gdn.py:50-63) with already re-parametrised beta [C] and gamma [C_out][C_in] (the module's own layout). */
+PC_API int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma,
                        int inverse, float* out, void* stream);
 
 /* Shifted-window attention core between the qkv and proj Linears (layers/win_attention.py:84-115,153-207).

@@ -45,7 +45,7 @@ const int CC_W[5] = {224, 176, 128, 64, 32};
 struct HostTensor { std::vector<uint8_t> data; std::vector<int64_t> shape; int dtype; };
 
 struct ConvW { float* w = nullptr; float* b = nullptr; int Cin = 0, Cout = 0, k = 0, kind = 0, layout = 0; };
-struct GdnW { float* beta = nullptr; float* gamma_t = nullptr; int C = 0; };
+struct GdnW { float* beta = nullptr; float* gamma = nullptr; int C = 0; };   // gamma [C_out][C_in], re-parametrised
 struct RuW { ConvW c0, c2, c4; };
 struct WamW { RuW a[3], b[3]; ConvW qkv, proj, out; float* bias = nullptr; int C = 0, ws = 0, shift = 0; };
 struct Stack5W { ConvW c[5]; };
@@ -204,9 +204,9 @@ int load_gdn(pc_codec* c, const std::string& p, int C, GdnW* out)
     std::vector<float> hb(C), hg((size_t)C * C);
     for (int i = 0; i < C; ++i) { const float v = std::max(f(beta)[i], f(bb)[0]); hb[i] = v * v - f(bp)[0]; }
     for (int i = 0; i < C; ++i)
-        for (int j = 0; j < C; ++j) { const float v = std::max(f(gamma)[(size_t)i * C + j], f(gb)[0]); hg[(size_t)j * C + i] = v * v - f(gp)[0]; }
+        for (int j = 0; j < C; ++j) { const float v = std::max(f(gamma)[(size_t)i * C + j], f(gb)[0]); hg[(size_t)i * C + j] = v * v - f(gp)[0]; }
     PCCHK(upload(c, hb, &out->beta));
-    PCCHK(upload(c, hg, &out->gamma_t));
+    PCCHK(upload(c, hg, &out->gamma));
     out->C = C;
     return PC_OK;
 }
@@ -341,7 +341,7 @@ int gdn(hipStream_t st, const GdnW& g, const float* x, int B, int H, int W, bool
     q.nseg = 1; q.seg[0].ptr = x; q.seg[0].ld = g.C; q.seg[0].nch = g.C; q.Cin = g.C;
     q.B = B; q.H = H; q.W = W; q.square = 1;
     fill_conv_taps(q, 1, 1);
-    q.w = g.gamma_t; q.bias = g.beta; q.Cout = g.C;
+    q.w = g.gamma; q.wlayout = 1; q.bias = g.beta; q.Cout = g.C;
     q.Ho = H; q.Wo = W; q.outH = H; q.outW = W; q.M = B * H * W;
     q.out = out; q.out_sc = 1; q.out_sx = g.C; q.out_sy = (int64_t)W * g.C; q.out_sb = (int64_t)H * W * g.C;
     q.epi = inverse ? PC_EPI_IGDN : PC_EPI_GDN; q.aux0 = x; q.ld0 = g.C;
@@ -605,11 +605,11 @@ extern "C" int pc_conv2d_nhwc(const float* x, int B, int H, int W, int Cin, cons
     return pc_conv_launch(q, (hipStream_t)stream);
 }
 
-extern "C" int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma_t, int inverse,
+extern "C" int pc_gdn_nhwc(const float* x, int B, int H, int W, int C, const float* beta, const float* gamma, int inverse,
                            float* out, void* stream)
 {
-    if (!x || !beta || !gamma_t || !out || C % 16) return PC_ERR_ARG;
-    GdnW g; g.beta = const_cast<float*>(beta); g.gamma_t = const_cast<float*>(gamma_t); g.C = C;
+    if (!x || !beta || !gamma || !out || C % 16) return PC_ERR_ARG;
+    GdnW g; g.beta = const_cast<float*>(beta); g.gamma = const_cast<float*>(gamma); g.C = C;
     return gdn((hipStream_t)stream, g, x, B, H, W, inverse != 0, out);
 }
 

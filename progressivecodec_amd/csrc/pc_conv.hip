@@ -36,21 +36,31 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-__device__ __forceinline__ float epilogue_value(const pc_conv_params& p, float v, int64_t pix, int n)
+// epilogue arithmetic on values already loaded (a0 / a1 = the aux tensors' elements at this output position)
+__device__ __forceinline__ float epilogue_apply(int epi, float v, float a0, float a1)
 {
-    switch (p.epi) {
+    switch (epi) {
     case PC_EPI_NONE: return v;
     case PC_EPI_GELU: return pc_geluf(v);
-    case PC_EPI_RES_GELU: return pc_geluf(v + p.aux0[pix * p.ld0 + n]);
-    case PC_EPI_RES: return p.aux0[pix * p.ld0 + n] + v;
-    case PC_EPI_GATE: return p.aux0[pix * p.ld0 + n] * pc_sigmoidf(v) + p.aux1[pix * p.ld1 + n];
-    case PC_EPI_GDN: return p.aux0[pix * p.ld0 + n] * pc_rsqrtf(v);
-    case PC_EPI_IGDN: return p.aux0[pix * p.ld0 + n] * sqrtf(v);
+    case PC_EPI_RES_GELU: return pc_geluf(v + a0);
+    case PC_EPI_RES: return a0 + v;
+    case PC_EPI_GATE: return a0 * pc_sigmoidf(v) + a1;
+    case PC_EPI_GDN: return a0 * pc_rsqrtf(v);
+    case PC_EPI_IGDN: return a0 * sqrtf(v);
     case PC_EPI_CLAMP01: return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
-    case PC_EPI_LRP: return p.aux0[pix * p.ld0 + n] + 0.5f * pc_tanhf(v);
-    case PC_EPI_LRP_ADD: return (p.aux0[pix * p.ld0 + n] + 0.5f * pc_tanhf(v)) + p.aux1[pix * p.ld1 + n];
+    case PC_EPI_LRP: return a0 + 0.5f * pc_tanhf(v);
+    case PC_EPI_LRP_ADD: return (a0 + 0.5f * pc_tanhf(v)) + a1;
     default: return v;
     }
+}
+__device__ __forceinline__ bool epilogue_uses_aux0(int epi) { return epi == PC_EPI_RES_GELU || epi == PC_EPI_RES || epi == PC_EPI_GATE || epi == PC_EPI_GDN || epi == PC_EPI_IGDN || epi == PC_EPI_LRP || epi == PC_EPI_LRP_ADD; }
+__device__ __forceinline__ bool epilogue_uses_aux1(int epi) { return epi == PC_EPI_GATE || epi == PC_EPI_LRP_ADD; }
+
+__device__ __forceinline__ float epilogue_value(const pc_conv_params& p, float v, int64_t pix, int n)
+{
+    const float a0 = epilogue_uses_aux0(p.epi) ? p.aux0[pix * p.ld0 + n] : 0.0f;
+    const float a1 = epilogue_uses_aux1(p.epi) ? p.aux1[pix * p.ld1 + n] : 0.0f;
+    return epilogue_apply(p.epi, v, a0, a1);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool SMALLC>
@@ -301,7 +311,7 @@ template <int NI, int MAXC> __device__ __forceinline__ void pc_wait_chunks(int c
 
 struct pc_run { const float* a_base; const float* w_base; int ld, nch, tap, pad; };   // one (tap, input segment) of the K loop
 
-template <int BK, int S, int WM, int WN, bool STAMPS>
+template <int BK, int S, int WM, int WN, bool STAMPS, bool SQ>
 __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_conv_params p)
 {
     constexpr int BM = 32 * WM, BN = 32 * WN, KQ = BK / 4;
@@ -476,7 +486,9 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         for (int g = 0; g < NG; ++g) {
             if (g + 1 < NG) { va[(g + 1) & 1] = A[(2 * (g + 1) + half) ^ a_swz]; vb[(g + 1) & 1] = Bp[(2 * (g + 1) + half) ^ b_swz]; }
             __builtin_amdgcn_sched_barrier(0);
-            const float4 x = va[g & 1], y = vb[g & 1];
+            float4 x = va[g & 1];
+            const float4 y = vb[g & 1];
+            if (SQ) { x.x *= x.x; x.y *= x.y; x.z *= x.z; x.w *= x.w; }     // GDN feeds x^2 (gdn.py:56)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc, 0, 0, 0);
@@ -506,7 +518,9 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     if (n >= p.Cout) return;
     const float bv = bias ? bias[n] : 0.0f;
     if (p.dense_out) {
-        // stride-1 layers storing a plain NHWC(-strided) tensor: the output pixel index is the GEMM row, no div/mod
+        // layers storing a plain NHWC(-strided) tensor on the GEMM's own pixel grid: the output pixel index is the GEMM row, no
+        // div/mod.  (Loading the 16 aux elements of a lane up front as independent loads was tried: +32 VGPRs cost occupancy
+        // and the 16x unrolled GELU code; GDN and the 1x1 layers got 8-16 % slower, profiles/r01_j_*.)
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= p.M) continue;
@@ -538,7 +552,7 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     }
 }
 
-template <int BK, int S, int WM, int WN>
+template <int BK, int S, int WM, int WN, bool SQ = false>
 hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
     constexpr int BM = 32 * WM, BN = 32 * WN;
@@ -547,7 +561,7 @@ hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
     const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
     dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ngroup == 2 ? 2 : p.nphase);
     const bool stamps = (p.dbg & 64) != 0;
-    auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true> : conv_igemm_dma_kernel<BK, S, WM, WN, false>;
+    auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true, SQ> : conv_igemm_dma_kernel<BK, S, WM, WN, false, SQ>;
     static bool attr_set[2] = {false, false};             // per instantiation: allow more than 64 KB of dynamic LDS
     if (lds > 48 * 1024 && !attr_set[stamps]) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
@@ -583,7 +597,7 @@ extern "C" __attribute__((visibility("default"))) int pc_debug_read_stamps(unsig
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
 {
     const long ktot = (long)(kind == 0 ? k * k : 9) * Cin;     // largest K of any output phase
-    return (Cin % 16 == 0 && Cout > 4 && ktot > 256) ? 1 : 0;
+    return (Cin % 16 == 0 && Cout > 4 && ktot >= 64) ? 1 : 0;
 }
 
 // Host-side validation + tile selection.  Returns a pc status code.
@@ -610,13 +624,13 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
     if (p.pixel_shuffle && (p.Cout % 4)) return PC_ERR_ARG;
 
     // Kernel selection (measured on MI355X with tools/conv_tune.py; profiles/r01_*):
-    //  * weight layout 1 (chosen at pack time by pc_conv_weight_layout: K per phase > 256, Cout > 4, Cin % 16 == 0):
+    //  * weight layout 1 (chosen at pack time by pc_conv_weight_layout: Cin % 16 == 0, Cout > 4; GDN's gamma is always layout 1):
     //    wave-specialised 64x64 LDS-DMA kernel, K-chunk 32, three LDS stages;
-    //  * weight layout 0: the plain BK=16 kernel (1x1 convs / GDN: epilogue-dominated; the 3-channel output layer;
-    //    the 3-channel input layer through the element-gather loader).
+    //  * weight layout 0: the plain BK=16 kernel -- the 3-channel output layer and the 3-channel input layer (element-gather
+    //    loader).  (1x1 convs and GDN moved to the LDS-DMA kernel: 17-25 % faster, profiles/r01_tune_tune27.log.)
     hipError_t e;
     if (p.wlayout == 1) {
-        if (p.smallc || p.square || (p.Cin % 16)) return PC_ERR_ARG;
+        if (p.smallc || (p.Cin % 16)) return PC_ERR_ARG;
         if (p.ngroup == 2 && (p.nphase != 1 || !p.g1_seg0 || !p.g1_w || !p.g1_out)) return PC_ERR_ARG;
         // Measured on MI355X (tools/conv_tune.py; profiles/r01_tune_tune18.log, tune25, tune26): K-chunk 32 with three LDS stages
         // (two chunks in flight) wins or ties on every layer shape of the codec, small and large grids alike -- 64-channel
@@ -624,10 +638,17 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         // instantiations stay reachable for tuning through PC_CONV_BK / PC_CONV_S.
         static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
         static const int s_env = [] { const char* v = std::getenv("PC_CONV_S"); return v ? std::atoi(v) : 0; }();
+        int chunks = 0;                                    // K-loop length of the longest phase, in 32-channel chunks
+        for (int ph = 0; ph < p.nphase; ++ph) {
+            int c = 0;
+            for (int sg = 0; sg < p.nseg; ++sg) c += (p.seg[sg].nch + 31) / 32;
+            chunks = std::max(chunks, c * p.ntap[ph]);
+        }
         const int bk = bk_env ? bk_env : 32;
-        const int S = s_env ? s_env : 3;
+        const int S = s_env ? s_env : (chunks <= 8 ? 2 : 3);   // 1x1 layers with K <= 256: two stages (nothing to keep in flight)
         e = hipErrorInvalidValue;
-#define PC_DMA_CASE(BK_, S_) if (bk == BK_ && S == S_) e = launch_dma<BK_, S_, 2, 2>(p, stream);
+        if (p.square) e = launch_dma<32, 2, 2, 2, true>(p, stream);        // GDN / IGDN: K = C <= 320
+#define PC_DMA_CASE(BK_, S_) else if (bk == BK_ && S == S_) e = launch_dma<BK_, S_, 2, 2>(p, stream);
         PC_DMA_CASE(32, 3) PC_DMA_CASE(32, 2) PC_DMA_CASE(32, 4) PC_DMA_CASE(64, 2) PC_DMA_CASE(64, 3)
 #undef PC_DMA_CASE
         if (e == hipErrorInvalidValue) return PC_ERR_ARG;

@@ -138,11 +138,10 @@ def test_gdn_bit_exact(inverse):
     x = rng.standard_normal((B, H, W, Cc)).astype(np.float32)
     beta = (1.0 + rng.random(Cc)).astype(np.float32)
     gamma = (0.1 * np.eye(Cc) + 0.004 * np.abs(rng.standard_normal((Cc, Cc)))).astype(np.float32)
-    gt = np.ascontiguousarray(gamma.T)
-    norm = lo.conv_nhwc(x, gt.reshape(1, Cc, Cc), [(0, 0)], 1, H, W, square=True) + beta.reshape(1, 1, 1, -1)
+    norm = lo.conv_nhwc(x, np.ascontiguousarray(gamma.T).reshape(1, Cc, Cc), [(0, 0)], 1, H, W, square=True) + beta.reshape(1, 1, 1, -1)
     want = x * lo.unary(norm, "sqrt" if inverse else "rsqrt")
     out = torch.empty(want.shape, device="cuda", dtype=torch.float32)
-    xd, bd, gd = dev(x), dev(beta), dev(gt)
+    xd, bd, gd = dev(x), dev(beta), dev(gamma)      # the C ABI takes gamma in the module's [C_out][C_in] layout
     check(L.pc_gdn_nhwc(P(xd), B, H, W, Cc, P(bd), P(gd), inverse, P(out), None))
     torch.cuda.synchronize()
     got = out.cpu().numpy()
