@@ -166,6 +166,24 @@ PC_API int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, con
                                const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
                                double quality, int mask_pol, float* x_hat, void* stream);
 
+/* Multi-level ("progressive") coding of one batch -- SURVEY.md section 8(f) rank 1.  The reference's harness calls
+ * compress() / decompress() once per mask level (training/step.py:322-337), recomputing g_a, h_a, the hyper-latent strings,
+ * h_s and the ten base slices (CHProg_cnn.py:692-767 / :855-904) although none of them depends on the level.  These entry
+ * points compute that shared part once and run only the enhancement chain (:775-845 / :930-983) and the synthesis transform
+ * per level.  Every string, mask and x_hat is identical, bit for bit, to what n_levels separate pc_codec_compress /
+ * pc_codec_decompress calls return.
+ *   string slots: slice 0..9 = base (shared), slice 10..19 of level l = slot 10 + 10*l + (slice-10); a level with
+ *   quality <= 0 has no enhancement strings.  masks_out: NULL or n_levels device pointers ([10][B][32][H/16][W/16] each, NULL
+ *   allowed per level; untouched for quality <= 0).  x_hat: device, [n_levels][B][3][64*zh][64*zw]. */
+PC_API int pc_codec_compress_levels(pc_codec* c, const float* x, int B, int H, int W, const double* qualities, int n_levels,
+                                    int mask_pol, float* const* masks_out, void* stream);
+/* string of level `level`: slice -1 = z, 0..9 = base (the same for every level), 10..19 = that level's enhancement */
+PC_API int pc_codec_get_level_string(const pc_codec* c, int level, int slice, int b, const uint8_t** data, size_t* len);
+/* y_strings / y_lens: [(10 + 10*n_levels) * B] in slot order (slot-major, then image); slots of quality-0 levels are ignored */
+PC_API int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens,
+                                      const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
+                                      const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream);
+
 /* Measurement aid (bench.py roofline leg): while profiling is on, every launch of the MFMA convolution kernel made by
  * compress()/decompress() is bracketed by HIP events on the call's stream; _end returns the launch count, the summed
  * event time and the algorithmic FLOPs (2*M*N*K per launch, no padding counted). */

@@ -18,7 +18,8 @@ EXPORTS = [
     "pc_gc_prep_encode", "pc_gc_prep_decode_index", "pc_gc_dequantize", "pc_codec_create", "pc_codec_destroy",
     "pc_codec_set_tensor", "pc_codec_set_tables", "pc_codec_finalize", "pc_codec_set_threads", "pc_codec_compress",
     "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
-    "pc_codec_profile_begin", "pc_codec_profile_end",
+    "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
+    "pc_codec_decompress_levels",
 ]
 
 
@@ -73,6 +74,9 @@ def lib():
         L.pc_codec_num_slices.argtypes = [vp]
         L.pc_codec_get_string.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.pc_codec_decompress.argtypes = [vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp]
+        L.pc_codec_compress_levels.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
+        L.pc_codec_get_level_string.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
+        L.pc_codec_decompress_levels.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.pc_codec_read_tap.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
         L.pc_codec_read_tap_i32.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
         L.pc_codec_profile_begin.argtypes = [vp]

@@ -82,8 +82,10 @@ struct pc_codec {
     // pinned host staging
     int32_t* h_sym = nullptr; int32_t* h_idx = nullptr; size_t h_cap = 0;
     // results of the last compress
-    int res_slices = 0, res_B = 0;
-    std::vector<std::vector<uint8_t>> y_strings;  // [slice*B + b]
+    int res_slices = 0, res_B = 0;               // res_slices = string slots: 10 base + 10 per coded level
+    std::vector<char> res_level_coded;            // per level of the last compress: enhancement strings present (quality > 0)
+    std::vector<hipEvent_t> lvl_events;           // D2H completion of the base pass / of each level
+    std::vector<std::vector<uint8_t>> y_strings;  // [slot*B + b]; slot = slice (base) or 10 + 10*level + (slice - 10)
     std::vector<std::vector<uint8_t>> z_strings;  // [b]
     int n_threads = 0;
     // optional per-launch profiling of the MFMA conv family (bench.py roofline leg)
@@ -820,6 +822,8 @@ struct ChainCtx {
     float *y, *lm, *ls, *yb, *ye, *mu, *scale, *thr, *masks;
     int32_t *sym, *idx;
     int mode; float q; bool enh;
+    int step0, step1;                           // chain steps to run: [0,10) base, [10,20) enhancement
+    int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
 };
 
 template <typename T> inline T* img(T* p, int b0, size_t per_image) { return p ? p + (size_t)b0 * per_image : nullptr; }
@@ -910,8 +914,7 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
 {
     pc_codec* c = k.c;
     const size_t pi = (size_t)k.HW;
-    const int n_steps = k.enh ? 2 * NS0 : NS0;
-    for (int step = 0; step < n_steps; ++step) {
+    for (int step = k.step0; step < k.step1; ++step) {
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         if (step < NS0) {                                                                // base slices, :729-764
@@ -939,8 +942,7 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     const size_t pi = (size_t)k.HW, per = (size_t)SLICE * k.HW;
     int32_t* h_idx = c->h_idx + (size_t)b0 * per;
     int32_t* h_sym = c->h_sym + (size_t)b0 * per;
-    const int n_steps = k.enh ? 2 * NS0 : NS0;
-    for (int step = 0; step < n_steps; ++step) {
+    for (int step = k.step0; step < k.step1; ++step) {
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         const bool e = step >= NS0;
@@ -950,7 +952,8 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
         HIPCHK(hipStreamSynchronize(sA));
         const auto td0 = std::chrono::steady_clock::now();
-        PCCHK(pc_rans_decode_batch(y_strings + (size_t)step * k.B + b0, y_lens + (size_t)step * k.B + b0, nb, h_idx, per,
+        const size_t slot = e ? (size_t)NS0 + (size_t)NS0 * k.level + i : (size_t)step;
+        PCCHK(pc_rans_decode_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx, per,
                                    c->gc.cdf.data(), c->gc.n, c->gc.stride, c->gc.len.data(), c->gc.off.data(), h_sym, nt));   // :894,969
         { std::lock_guard<std::mutex> lk(c->buf_mu); c->t_host_decode_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); }
         HIPCHK(hipMemcpyAsync(k.sym + so, h_sym, per * nb * 4, hipMemcpyHostToDevice, sA));
@@ -1015,19 +1018,54 @@ int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* con
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------- compress
-extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
-                                 float* masks_out, void* stream)
+namespace {
+
+// host rANS of `n_slots` x B y-streams (symbols / indexes at hs / hi, [slot][B][32*HW]) into string slots first_slot..., plus the B
+// z-streams when z_sym != nullptr   (entropy_models.py:226-235 -> compressai.ans)
+int encode_streams(pc_codec* c, const int32_t* hs, const int32_t* hi, int first_slot, int n_slots, int B, size_t per,
+                   const int32_t* z_sym, const int32_t* z_idx, size_t per_z)
 {
-    if (!c || !x || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
+    std::atomic<int> rc{PC_OK};
+    const size_t n_y_jobs = (size_t)n_slots * B;
+    auto job = [&](size_t j) {
+        const bool is_z = j >= n_y_jobs;
+        const size_t n = is_z ? per_z : per;
+        const int32_t* sym = is_z ? z_sym + (j - n_y_jobs) * per_z : hs + j * per;
+        const int32_t* idx = is_z ? z_idx + (j - n_y_jobs) * per_z : hi + j * per;
+        const Tables& t = is_z ? c->eb : c->gc;
+        std::vector<uint8_t>& dst = is_z ? c->z_strings[j - n_y_jobs] : c->y_strings[(size_t)first_slot * B + j];
+        dst.resize(pc_rans_bound(n));
+        size_t len = 0;
+        const int r = pc_rans_encode_with_indexes(sym, idx, n, t.cdf.data(), t.n, t.stride, t.len.data(), t.off.data(), dst.data(),
+                                                  dst.size(), &len);
+        if (r != PC_OK) rc = r;
+        dst.resize(len);
+    };
+    const size_t n_jobs = n_y_jobs + (z_sym ? (size_t)B : 0);
+    if (c->n_threads == 1) for (size_t j = 0; j < n_jobs; ++j) job(j);
+    else pc::default_pool().parallel_for(n_jobs, job);
+    return rc;
+}
+
+// compress() for a list of mask levels.  Everything that does not depend on the level -- g_a, h_a, the hyper-latent
+// strings, h_s and the ten base slices (CHProg_cnn.py:692-767) -- runs once; the enhancement chain (:775-845) runs once per
+// level with quality > 0.  The GPU always has the next pass queued while the host entropy-codes the previous one:
+//   GPU : g_a h_a h_s | base chain | D2H | enh chain L0 | D2H | enh chain L1 | D2H | ...
+//   host:                              wait, rANS base + z    wait, rANS L0        wait, rANS L1
+// (two pinned staging buffers for the enhancement symbols, used alternately).
+int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double* qualities, int n_levels, int mask_pol,
+                  float* const* masks_out, hipStream_t st)
+{
+    if (!c || !x || !qualities || n_levels < 1 || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
     if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok()) return PC_ERR_STATE;
     if (c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
     g_prof = c->profile ? c : nullptr;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
-    const int n_slices = quality <= 0 ? NS0 : 2 * NS0;
+    bool any_enh = false;
+    for (int l = 0; l < n_levels; ++l) any_enh = any_enh || !(qualities[l] <= 0);
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
 
     ChainCtx k;
@@ -1047,67 +1085,128 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
     PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
     PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
-    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M; k.masks = masks_out; k.enh = n_slices > NS0;
-    k.mode = k.enh ? mask_mode_for(mask_pol, quality, &k.q) : 0;
+    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
+
+    const size_t n_half = (size_t)NS0 * M * SLICE, n_z = (size_t)B * ZHW * NCH;      // symbols of one pass / of z
+    const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
+    PCCHK(ensure_host_staging(c, 3 * n_half + n_z));                                // [base][enh A][enh B][z]
+    while ((int)c->lvl_events.size() < n_levels + 1) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->lvl_events.push_back(e);
+    }
+    c->res_slices = NS0 + NS0 * n_levels; c->res_B = B;
+    c->res_level_coded.assign(n_levels, 0);
+    c->y_strings.assign((size_t)c->res_slices * B, {});
+    c->z_strings.assign(B, {});
+    static const bool timing = std::getenv("PC_TIMING") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double t_host = 0.0;
 
     PCCHK(g_a(c, st, x, B, H, W, k.y));                                                  // :692
     PCCHK(h_a(c, st, k.y, B, h, w, z));                                                  // :700
     PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :702-704
-    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :705-715
-    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :729-845
-    static const bool timing = std::getenv("PC_TIMING") != nullptr;
-    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t_launch = now();
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, any_enh ? 1.0 : 0.0, k.lm, k.ls));              // :705-715
+    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :729-767
+    HIPCHK(hipMemcpyAsync(c->h_sym, k.sym, n_half * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_half * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_sym + 3 * n_half, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipEventRecord(c->lvl_events[0], st));
 
-    // ---- symbols/indexes to the host, rANS on the thread pool  (entropy_models.py:226-235)
-    const size_t n_y = (size_t)n_slices * M * SLICE, n_z = (size_t)B * ZHW * NCH;
-    PCCHK(ensure_host_staging(c, n_y + n_z));
-    HIPCHK(hipMemcpyAsync(c->h_sym, k.sym, n_y * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_y * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_sym + n_y, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    const double t_sync = now();
-    for (size_t e = 0; e < n_z; ++e) c->h_idx[n_y + e] = (int32_t)((e / ZHW) % NCH);     // EntropyBottleneck._build_indexes :492-502
-    c->res_slices = n_slices; c->res_B = B;
-    c->y_strings.assign((size_t)n_slices * B, {});
-    c->z_strings.assign(B, {});
-    const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
-    std::atomic<int> rc{PC_OK};
-    auto job = [&](size_t j) {
-        const bool is_z = j >= (size_t)n_slices * B;
-        const size_t n = is_z ? per_z : per;
-        const size_t off = is_z ? n_y + (j - (size_t)n_slices * B) * per_z : j * per;
-        const Tables& t = is_z ? c->eb : c->gc;
-        std::vector<uint8_t>& dst = is_z ? c->z_strings[j - (size_t)n_slices * B] : c->y_strings[j];
-        dst.resize(pc_rans_bound(n));
-        size_t len = 0;
-        const int r = pc_rans_encode_with_indexes(c->h_sym + off, c->h_idx + off, n, t.cdf.data(), t.n, t.stride, t.len.data(),
-                                                  t.off.data(), dst.data(), dst.size(), &len);
-        if (r != PC_OK) rc = r;
-        dst.resize(len);
+    // what the host still has to entropy-code once its event has fired: -1 = base + z, else the level index
+    int pending = -1, pending_buf = 0, n_coded = 0;
+    int rc = PC_OK;
+    auto drain = [&](int what, int bufsel) -> int {
+        const double th = now();
+        int r;
+        if (what < 0) {
+            HIPCHK(hipEventSynchronize(c->lvl_events[0]));
+            for (size_t e = 0; e < n_z; ++e) c->h_idx[3 * n_half + e] = (int32_t)((e / ZHW) % NCH);   // EntropyBottleneck._build_indexes :492-502
+            r = encode_streams(c, c->h_sym, c->h_idx, 0, NS0, B, per, c->h_sym + 3 * n_half, c->h_idx + 3 * n_half, per_z);
+        } else {
+            HIPCHK(hipEventSynchronize(c->lvl_events[1 + what]));
+            const size_t off = (size_t)(1 + bufsel) * n_half;
+            r = encode_streams(c, c->h_sym + off, c->h_idx + off, NS0 + NS0 * what, NS0, B, per, nullptr, nullptr, per_z);
+        }
+        t_host += now() - th;
+        return r;
     };
-    const size_t n_jobs = (size_t)n_slices * B + B;
-    if (c->n_threads == 1) for (size_t j = 0; j < n_jobs; ++j) job(j);
-    else pc::default_pool().parallel_for(n_jobs, job);
-    if (timing) std::fprintf(stderr, "[pcodec] compress: launches done -> GPU+D2H done %.2f ms, host rANS encode %.2f ms (%zu streams)\n",
-                             t_sync - t_launch, now() - t_sync, n_jobs);
+    for (int l = 0; l < n_levels; ++l) {
+        if (qualities[l] <= 0) continue;                                                 // base only: nothing level-specific to code
+        k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
+        k.mode = mask_mode_for(mask_pol, qualities[l], &k.q);
+        k.masks = masks_out ? masks_out[l] : nullptr;
+        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :775-845
+        const int bufsel = n_coded & 1;
+        const size_t off = (size_t)(1 + bufsel) * n_half;
+        HIPCHK(hipMemcpyAsync(c->h_sym + off, k.sym + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(c->h_idx + off, k.idx + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c->lvl_events[1 + l], st));
+        c->res_level_coded[l] = 1;
+        ++n_coded;
+        // this level is queued on the GPU: entropy-code the pass before it meanwhile (its staging buffer is the other one)
+        const int r = drain(pending, pending_buf);
+        if (r != PC_OK) rc = r;
+        pending = l; pending_buf = bufsel;
+    }
+    const int r = drain(pending, pending_buf);
+    if (r != PC_OK) rc = r;
+    HIPCHK(hipStreamSynchronize(st));                                                    // masks_out complete for the caller
+    if (timing) std::fprintf(stderr, "[pcodec] compress: %d level(s), %d coded; total %.2f ms of which host rANS + waits %.2f ms\n", n_levels,
+                             n_coded, now() - t0, t_host);
     return rc;
 }
 
-// ---------------------------------------------------------------------------------------------- decompress
-extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens, int n_slices,
-                                   const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
-                                   double quality, int mask_pol, float* x_hat, void* stream)
+}  // namespace
+
+extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
+                                 float* masks_out, void* stream)
 {
-    if (!c || !y_strings || !y_lens || !z_strings || !z_lens || !x_hat || B <= 0 || zh <= 0 || zw <= 0) return PC_ERR_ARG;
+    float* const m[1] = {masks_out};
+    const int r = compress_impl(c, x, B, H, W, &quality, 1, mask_pol, masks_out ? m : nullptr, (hipStream_t)stream);
+    if (r == PC_OK && quality <= 0) c->res_slices = NS0;        // compress() at quality 0 returns the ten base slices only
+    return r;
+}
+
+extern "C" int pc_codec_compress_levels(pc_codec* c, const float* x, int B, int H, int W, const double* qualities, int n_levels,
+                                        int mask_pol, float* const* masks_out, void* stream)
+{
+    return compress_impl(c, x, B, H, W, qualities, n_levels, mask_pol, masks_out, (hipStream_t)stream);
+}
+
+extern "C" int pc_codec_get_level_string(const pc_codec* c, int level, int slice, int b, const uint8_t** data, size_t* len)
+{
+    if (!c || !data || !len || b < 0 || b >= c->res_B || level < 0 || level >= (int)c->res_level_coded.size()) return PC_ERR_ARG;
+    const std::vector<uint8_t>* s;
+    if (slice == -1) s = &c->z_strings[b];
+    else if (slice >= 0 && slice < NS0) s = &c->y_strings[(size_t)slice * c->res_B + b];
+    else if (slice < 2 * NS0 && c->res_level_coded[level]) s = &c->y_strings[((size_t)NS0 + (size_t)NS0 * level + (slice - NS0)) * c->res_B + b];
+    else return PC_ERR_ARG;
+    *data = s->data(); *len = s->size();
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decompress
+namespace {
+
+// decompress() for a list of levels: z, h_s and the ten base slices are decoded once (:855-904); every level with quality > 0
+// decodes its own enhancement chain (:930-983) and runs the enhancement synthesis; a level with quality 0 runs the base synthesis
+// (:907-916).  y_strings / y_lens: [(10 + 10 * n_levels) * B] in the slot order of compress (slots of quality-0 levels are ignored).
+int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens, const uint8_t* const* z_strings,
+                    const size_t* z_lens, int B, int zh, int zw, const double* qualities, int n_levels, int mask_pol, float* x_hat,
+                    hipStream_t st)
+{
+    if (!c || !y_strings || !y_lens || !z_strings || !z_lens || !x_hat || !qualities || n_levels < 1 || B <= 0 || zh <= 0 || zw <= 0) return PC_ERR_ARG;
     if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
-    if (n_slices < (quality == 0 ? NS0 : 2 * NS0)) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
-    hipStream_t st = (hipStream_t)stream;
     g_prof = c->profile ? c : nullptr;
     const int h = 4 * zh, w = 4 * zw, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
+    bool any_enh = false;
+    for (int l = 0; l < n_levels; ++l) any_enh = any_enh || qualities[l] != 0;
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
 
     ChainCtx k;
@@ -1125,8 +1224,7 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
     PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
     PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
-    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M; k.enh = quality != 0;
-    k.mode = k.enh ? mask_mode_for(mask_pol, quality, &k.q) : 0;
+    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
     PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
     const int nt = c->n_threads == 1 ? 1 : 0;
@@ -1138,12 +1236,41 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
     HIPCHK(hipMemcpyAsync(z_sym, c->h_sym, per_z * B * 4, hipMemcpyHostToDevice, st));
     PCCHK(pc_eb_dequant_launch(z_sym, B, ZHW, NCH, c->medians, z_hat, st));
     HIPCHK(hipStreamSynchronize(st));   // h_sym is reused by the lanes
-    PCCHK(hyper(c, st, z_hat, B, zh, zw, quality, k.lm, k.ls));                          // :856-867
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, any_enh ? 1.0 : 0.0, k.lm, k.ls));              // :856-867
     c->t_host_decode_ms = 0.0;
-    PCCHK(run_chain(k, st, true, y_strings, y_lens));                                    // :874-983
-    if (std::getenv("PC_TIMING")) std::fprintf(stderr, "[pcodec] decompress: host rANS decode (summed over lanes) %.2f ms\n", c->t_host_decode_ms);
-    PCCHK(g_s(c, st, c->gs[k.enh ? 1 : 0], k.enh ? k.ye : k.yb, B, h, w, x_hat));       // :907-916 / :986-990
+    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+    PCCHK(run_chain(k, st, true, y_strings, y_lens));                                    // :874-904
+    const size_t img_elems = (size_t)B * 3 * (16 * h) * (16 * w);
+    for (int l = 0; l < n_levels; ++l) {
+        float* out = x_hat + (size_t)l * img_elems;
+        if (qualities[l] == 0) {
+            PCCHK(g_s(c, st, c->gs[0], k.yb, B, h, w, out));                             // :907-916
+            continue;
+        }
+        k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
+        k.mode = mask_mode_for(mask_pol, qualities[l], &k.q);
+        PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :930-983
+        PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990
+    }
+    if (std::getenv("PC_TIMING")) std::fprintf(stderr, "[pcodec] decompress: %d level(s), host rANS decode (summed over lanes) %.2f ms\n", n_levels, c->t_host_decode_ms);
     return PC_OK;
+}
+
+}  // namespace
+
+extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens, int n_slices,
+                                   const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
+                                   double quality, int mask_pol, float* x_hat, void* stream)
+{
+    if (n_slices < (quality == 0 ? NS0 : 2 * NS0)) return PC_ERR_ARG;
+    return decompress_impl(c, y_strings, y_lens, z_strings, z_lens, B, zh, zw, &quality, 1, mask_pol, x_hat, (hipStream_t)stream);
+}
+
+extern "C" int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens,
+                                          const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
+                                          const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream)
+{
+    return decompress_impl(c, y_strings, y_lens, z_strings, z_lens, B, zh, zw, qualities, n_levels, mask_pol, x_hat, (hipStream_t)stream);
 }
 
 extern "C" int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap, size_t* n)

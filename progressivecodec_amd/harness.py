@@ -24,10 +24,14 @@ def compute_padding(in_h, in_w, min_div=64):
     return (left, right, top, bottom), (-left, -right, -top, -bottom)
 
 
-def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda"):
+def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda", shared_base=False):
     """images: iterable of [1,3,H,W] (or [3,H,W]) float tensors in [0,1].
     Returns (bpp[level], psnr[level], dec_time[level]) averaged over the images, as step.py:404 does,
-    plus the per-image table."""
+    plus the per-image table.
+
+    shared_base=True codes all levels of an image with model.compress_levels / decompress_levels: g_a, h_a, z, h_s and
+    the ten base slices run once per image instead of once per level.  The RD table is
+    identical; dec_time is then the time of the joint decode divided by the number of levels."""
     import torch
     import torch.nn.functional as F
     pr_list = list(PR_LIST if pr_list is None else pr_list)
@@ -39,6 +43,23 @@ def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", de
             h, w = x.shape[2:]
             pad, unpad = compute_padding(h, w, 64)
             x_padded = F.pad(x, pad, mode="constant", value=0)
+            if shared_base:
+                datas = model.compress_levels(x_padded, pr_list, mask_pol=mask_pol)
+                if x.is_cuda:
+                    torch.cuda.synchronize()
+                t0 = time.time()
+                outs = model.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], pr_list, mask_pol=mask_pol)
+                if x.is_cuda:
+                    torch.cuda.synchronize()
+                dec_time = (time.time() - t0) / len(pr_list)
+                for p, data, out_dec in zip(pr_list, datas, outs):
+                    x_hat = F.pad(out_dec["x_hat"], unpad).clamp_(0, 1)
+                    mse = torch.mean((x - x_hat) ** 2).item()
+                    psnr = -10.0 * math.log10(mse) if mse > 0 else float("inf")
+                    y_strings, z_strings = data["strings"]
+                    nbytes = sum(len(s[0]) for s in y_strings) + sum(len(s) for s in z_strings)
+                    rows.append({"quality": p, "bpp": 8.0 * nbytes / (h * w), "psnr": psnr, "dec_time": dec_time})
+                continue
             for p in pr_list:
                 data = model.compress(x_padded, quality=p, mask_pol=mask_pol)
                 if x.is_cuda:

@@ -187,6 +187,95 @@ class ChannelProgresssiveWACNN:
         del keep
         return {"x_hat": x_hat}
 
+    # ------------------------------------------------------------------ multi-level (shared base) coding
+    def compress_levels(self, x, qualities, mask_pol=None):
+        """compress() for a list of mask levels with the level-independent part (g_a, h_a, z, h_s, the ten base slices;
+        CHProg_cnn.py:692-767) computed once -- SURVEY.md section 8(f) rank 1.  Returns one compress()-style dictionary per
+        level; the z strings and the ten base y strings are the same objects in every entry, and every entry equals what
+        compress(x, q, mask_pol) returns for that level."""
+        import torch
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in _MASK_POL:
+            raise NotImplementedError(f"mask policy {mask_pol!r}")
+        if self._gc is None or self._eb is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("Invalid `inputs` size. Expected a [B,3,H,W] tensor.")
+        qualities = [float(q) for q in qualities]
+        if not qualities:
+            raise ValueError("at least one level")
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (pad as training/step.py:318 does)")
+        x = x.to(self.device, torch.float32).contiguous()
+        h, w = H // 16, W // 16
+        L = len(qualities)
+        masks = [torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if q > 0 else None for q in qualities]
+        mp = (C.c_void_p * L)(*[m.data_ptr() if m is not None else None for m in masks])
+        qa = (C.c_double * L)(*qualities)
+        check(lib().pc_codec_compress_levels(self._h, C.c_void_p(x.data_ptr()), B, H, W, qa, L, _MASK_POL[mask_pol], mp, self._stream()),
+              "pc_codec_compress_levels")
+        p, n = C.c_void_p(), C.c_size_t()
+
+        def get(lv, s, b):
+            check(lib().pc_codec_get_level_string(self._h, lv, s, b, C.byref(p), C.byref(n)), "pc_codec_get_level_string")
+            return C.string_at(p, n.value)
+
+        z_strings = [get(0, -1, b) for b in range(B)]
+        base = [[get(0, s, b) for b in range(B)] for s in range(10)]
+        out = []
+        for lv, q in enumerate(qualities):
+            enh = [[get(lv, s, b) for b in range(B)] for s in range(10, 20)] if q > 0 else []
+            out.append({"strings": [base + enh, z_strings], "shape": torch.Size([H // 64, W // 64]),
+                        "masks": [masks[lv][i] for i in range(10)] if masks[lv] is not None else []})
+        return out
+
+    def decompress_levels(self, strings_per_level, shape, qualities, mask_pol=None):
+        """decompress() for a list of levels of the same images: z, h_s and the ten base slices are decoded once
+        (CHProg_cnn.py:855-904), each level decodes its enhancement chain and runs its synthesis transform.
+        strings_per_level[l] = [y_strings, z_strings] as returned by compress()/compress_levels() for level l (the base and z
+        strings are taken from entry 0).  Returns one {"x_hat"} dictionary per level, equal to decompress() of that level."""
+        import torch
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in _MASK_POL:
+            raise NotImplementedError(f"mask policy {mask_pol!r}")
+        if self._gc is None or self._eb is None:
+            raise ValueError("Uninitialized CDFs. Run update() first")
+        qualities = [float(q) for q in qualities]
+        L = len(qualities)
+        if L == 0 or len(strings_per_level) != L:
+            raise ValueError("one [y_strings, z_strings] entry per level")
+        for st in strings_per_level:
+            if not isinstance(st, (tuple, list)) or len(st) != 2:
+                raise ValueError("Invalid `strings` parameter type.")
+        z_strings = list(strings_per_level[0][1])
+        B = len(z_strings)
+        zh, zw = int(shape[0]), int(shape[1])
+        slots = [list(sl) for sl in strings_per_level[0][0][:10]]
+        if len(slots) != 10:
+            raise ValueError("Invalid strings or indexes parameters")
+        for lv, q in enumerate(qualities):
+            ys = strings_per_level[lv][0]
+            if q != 0:
+                if len(ys) < 20:
+                    raise ValueError("Invalid strings or indexes parameters")
+                slots += [list(sl) for sl in ys[10:20]]
+            else:
+                slots += [[b""] * B for _ in range(10)]
+        if any(len(sl) != B for sl in slots):
+            raise ValueError("Invalid strings or indexes parameters")
+        flat = [s for sl in slots for s in sl]
+        yp = (C.c_char_p * len(flat))(*flat)
+        yl = (C.c_size_t * len(flat))(*[len(s) for s in flat])
+        zp = (C.c_char_p * B)(*z_strings)
+        zl = (C.c_size_t * B)(*[len(s) for s in z_strings])
+        qa = (C.c_double * L)(*qualities)
+        x_hat = torch.empty((L, B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
+        check(lib().pc_codec_decompress_levels(self._h, yp, yl, zp, zl, B, zh, zw, qa, L, _MASK_POL[mask_pol],
+                                               C.c_void_p(x_hat.data_ptr()), self._stream()), "pc_codec_decompress_levels")
+        del flat
+        return [{"x_hat": x_hat[lv]} for lv in range(L)]
+
     # ------------------------------------------------------------------ test taps
     def read_tap(self, name, dtype=np.float32):
         n = C.c_size_t()

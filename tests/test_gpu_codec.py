@@ -185,3 +185,58 @@ def test_large_tiles_round_trip_properties():
         assert ((s - 0.2 * k).abs() <= 4).all(), s
     bpp = bpp_of(out["strings"], 2, 1024, 1024)
     assert 1.0 < bpp < 10.0
+
+
+def test_shared_base_levels_equal_per_level_calls():
+    """compress_levels / decompress_levels compute the level-independent part once; every
+    string, mask and x_hat must equal, bit for bit, what one compress()/decompress() call per level returns."""
+    net = gpu_codec()
+    x = inputs(2, 128, 192, 55).cuda()
+    levels = [0, 0.05, 0.5, 0, 2, 10]
+    datas = net.compress_levels(x, levels, "point-based-std")
+    assert len(datas) == len(levels)
+    singles = [net.compress(x, q, "point-based-std") for q in levels]
+    for q, d, s in zip(levels, datas, singles):
+        assert d["strings"][1] == s["strings"][1], f"z strings differ at level {q}"
+        assert d["strings"][0] == s["strings"][0], f"y strings differ at level {q}"
+        assert tuple(d["shape"]) == tuple(s["shape"])
+        assert len(d["masks"]) == len(s["masks"])
+        for m, ms in zip(d["masks"], s["masks"]):
+            assert torch.equal(m, ms)
+    assert all(d["strings"][0][i] is datas[0]["strings"][0][i] for d in datas for i in range(10))   # base stored once
+    outs = net.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], levels, "point-based-std")
+    for q, o, s in zip(levels, outs, singles):
+        ref = net.decompress(s["strings"], s["shape"], q, "point-based-std")["x_hat"]
+        assert torch.equal(o["x_hat"], ref), f"x_hat differs at level {q}"
+    # a subset / different order of levels decodes to the same pictures
+    sub = [4, 1]
+    outs2 = net.decompress_levels([datas[i]["strings"] for i in sub], datas[0]["shape"], [levels[i] for i in sub], "point-based-std")
+    for j, i in enumerate(sub):
+        assert torch.equal(outs2[j]["x_hat"], outs[i]["x_hat"])
+
+
+def test_container_round_trip_through_the_codec():
+    from progressivecodec_amd import container as ct
+    net = gpu_codec()
+    x = inputs(2, 64, 128, 56).cuda()
+    levels = [0, 0.5, 3]
+    datas = net.compress_levels(x, levels, "point-based-std")
+    outs = net.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], levels, "point-based-std")
+    for b in range(2):
+        buf = ct.pack([d["strings"] for d in datas], datas[0]["shape"], levels, (64, 128), image_index=b)
+        strings, shape, q, size, mp = ct.unpack(buf)
+        dec = net.decompress_levels(strings, shape, q, mp)
+        for lv in range(len(levels)):
+            assert torch.equal(dec[lv]["x_hat"][0], outs[lv]["x_hat"][b])
+            assert ct.payload_bytes(buf, lv) == sum(len(sl[b]) for sl in datas[lv]["strings"][0]) + len(datas[lv]["strings"][1][b])
+        one, shape1, q1, _, _ = ct.unpack(buf, [2])           # a reader that wants the last level only
+        assert torch.equal(net.decompress(one[0], shape1, q1[0], mp)["x_hat"][0], outs[2]["x_hat"][b])
+
+
+def test_harness_shared_base_gives_the_same_rd_table():
+    from progressivecodec_amd.harness import PR_LIST, compress_with_ac
+    imgs = [inputs(1, 64, 128, 31), inputs(1, 96, 72, 32, "smooth")]
+    a = compress_with_ac(gpu_codec(), imgs, PR_LIST)
+    b = compress_with_ac(gpu_codec(), imgs, PR_LIST, shared_base=True)
+    assert a[0] == b[0] and a[1] == b[1]
+    assert [(r["quality"], r["bpp"], r["psnr"]) for r in a[3]] == [(r["quality"], r["bpp"], r["psnr"]) for r in b[3]]
