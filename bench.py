@@ -143,14 +143,16 @@ def main():
     check(lib().pc_codec_profile_end(h, C.byref(nl), C.byref(ms), C.byref(fl)))
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     # HBM bytes per launch cannot be read inside this process: they come from the committed rocprofv3 PMC passes of this
-    # same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/r01_e_hbm_traffic.json), or null
+    # same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/r*_hbm_traffic.json, folded by tools/pmc_traffic.py), or null
     traffic, traffic_src = None, None
-    tj = os.path.join(ROOT, "profiles", "r01_e_hbm_traffic.json")
-    if os.path.exists(tj) and B == 32 and S == 256:
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))      # newest round / letter last
+    tj = cands[-1] if cands else ""
+    if tj and B == 32 and S == 256:
         fam = json.load(open(tj))["families"]
         n = sum(f["launches_per_2_steps"] for k, f in fam.items() if k.startswith("conv_igemm"))
         traffic = round(sum(f["launches_per_2_steps"] * f["hbm_bytes_per_launch"] for k, f in fam.items() if k.startswith("conv_igemm")) / n)
-        traffic_src = "profiles/r01_e_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
+        traffic_src = f"profiles/{os.path.basename(tj)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
     roofline = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",

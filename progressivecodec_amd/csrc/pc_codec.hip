@@ -50,7 +50,7 @@ struct RuW { ConvW c0, c2, c4; };
 struct WamW { RuW a[3], b[3]; ConvW qkv, proj, out; float* bias = nullptr; int C = 0, ws = 0, shift = 0; };
 struct Stack5W { ConvW c[5]; };
 struct HsW { ConvW c0, c2, c4, c6, c8; };
-struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };
+struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };   // d8: the 192 -> 3 deconv in sub-pixel form (load_deconv3_subpixel)
 
 struct Tables {
     std::vector<int32_t> cdf, len, off;
@@ -178,6 +178,37 @@ int load_conv(pc_codec* c, const std::string& p, int Cin, int Cout, int k, int k
     return PC_OK;
 }
 
+// The last layer of g_s, ConvTranspose2d(192, 3, 5, s2, p2, op1) (models/utils.py:196, CHProg_cnn.py:160): with three output
+// channels a GEMM over output phases wastes 29 of every 32 MFMA columns (2.0 ms per Config-2 batch).  Sub-pixel form instead: ONE
+// stride-1 conv over the 3x3 input neighbourhood with 12 virtual channels n = c*4 + py*2 + px, stored through the PixelShuffle
+// epilogue; weight (tap (dy,dx), n) = W[ci][c][py+2-2dy][px+2-2dx] where that kernel index exists, else 0.  Taps are visited
+// dy = +1,0,-1 (outer), dx = +1,0,-1 (inner), so for every phase the taps it really has appear in ascending (ky,kx) -- the
+// contract's order for a transposed-conv phase -- and a zero-weight tap leaves the fmaf chain's value unchanged: bit-identical
+// to the four-phase form (tests/test_gpu_codec.py vs the oracle's four-phase restatement).
+int load_deconv3_subpixel(pc_codec* c, const std::string& p, int Cin, ConvW* out)
+{
+    const HostTensor* w = find(c, p + ".weight", PC_F32, {Cin, 3, 5, 5});
+    const HostTensor* b = find(c, p + ".bias", PC_F32, {3});
+    if (!w || !b || Cin % 16) { std::fprintf(stderr, "[pcodec] missing/mis-shaped tensor %s\n", p.c_str()); return PC_ERR_MISSING; }
+    const float* W = reinterpret_cast<const float*>(w->data.data());
+    std::vector<float> packed((size_t)9 * 12 * Cin, 0.0f);                    // layout 1: [tap][n][ci]
+    for (int t = 0; t < 9; ++t) {
+        const int dy = 1 - t / 3, dx = 1 - t % 3;
+        for (int n = 0; n < 12; ++n) {
+            const int cch = n >> 2, py = (n >> 1) & 1, px = n & 1;
+            const int ky = py + 2 - 2 * dy, kx = px + 2 - 2 * dx;
+            if (ky < 0 || ky >= 5 || kx < 0 || kx >= 5) continue;
+            for (int ci = 0; ci < Cin; ++ci) packed[((size_t)t * 12 + n) * Cin + ci] = W[(((size_t)ci * 3 + cch) * 5 + ky) * 5 + kx];
+        }
+    }
+    PCCHK(upload(c, packed, &out->w));
+    std::vector<float> bias(12);
+    for (int n = 0; n < 12; ++n) bias[n] = reinterpret_cast<const float*>(b->data.data())[n >> 2];
+    PCCHK(upload(c, bias, &out->b));
+    out->Cin = Cin; out->Cout = 12; out->k = 3; out->kind = 0; out->layout = 1;
+    return PC_OK;
+}
+
 int load_linear(pc_codec* c, const std::string& p, int Cin, int Cout, ConvW* out)     // nn.Linear weight [out][in]
 {
     const HostTensor* w = find(c, p + ".weight", PC_F32, {Cout, Cin});
@@ -274,7 +305,7 @@ void fill_conv_taps(pc_conv_params& q, int k, int stride)
     for (int ky = 0; ky < k; ++ky)
         for (int kx = 0; kx < k; ++kx) {
             const int t = ky * k + kx;
-            q.dy[0][t] = (int8_t)(ky - pad); q.dx[0][t] = (int8_t)(kx - pad); q.wtap[0][t] = t;
+            q.dy[0][t] = (ky - pad); q.dx[0][t] = (kx - pad); q.wtap[0][t] = t;
         }
     q.osy = q.osx = 1; q.ooy[0] = q.oox[0] = 0;
 }
@@ -288,7 +319,7 @@ void fill_deconv_taps(pc_conv_params& q)   // ConvTranspose2d(5, s2, p2, op1) as
             int t = 0;
             for (int ky = py; ky < 5; ky += 2)
                 for (int kx = px; kx < 5; kx += 2) {
-                    q.dy[ph][t] = (int8_t)((py + 2 - ky) / 2); q.dx[ph][t] = (int8_t)((px + 2 - kx) / 2);
+                    q.dy[ph][t] = ((py + 2 - ky) / 2); q.dx[ph][t] = ((px + 2 - kx) / 2);
                     q.wtap[ph][t] = ky * 5 + kx;
                     ++t;
                 }
@@ -491,15 +522,17 @@ int g_s(pc_codec* c, hipStream_t st, const GsW& g, const float* yhat, int B, int
     PCCHK(wam(c, st, g.w5, t2, B, 4 * h, 4 * w, t1));
     PCCHK(conv(st, g.d6, {{t1, NCH, NCH}}, B, 4 * h, 4 * w, 1, t2, NCH, PC_EPI_NONE));
     PCCHK(gdn(st, g.g7, t2, B, 8 * h, 8 * w, true, t1));
-    {   // deconv 192 -> 3, output written NCHW with clamp
+    {   // deconv 192 -> 3 in sub-pixel form (load_deconv3_subpixel), output written NCHW with clamp
         pc_conv_params q;
         std::memset(&q, 0, sizeof(q));
         const int H = 8 * h, W = 8 * w;
         q.nseg = 1; q.seg[0].ptr = t1; q.seg[0].ld = NCH; q.seg[0].nch = NCH; q.Cin = NCH;
         q.B = B; q.H = H; q.W = W;
-        fill_deconv_taps(q);
-        q.w = g.d8.w; q.bias = g.d8.b; q.Cout = 3;
+        q.nphase = 1; q.ntap[0] = 9; q.stride = 1; q.osy = q.osx = 1;
+        for (int t = 0; t < 9; ++t) { q.dy[0][t] = 1 - t / 3; q.dx[0][t] = 1 - t % 3; q.wtap[0][t] = t; }
+        q.w = g.d8.w; q.wlayout = 1; q.bias = g.d8.b; q.Cout = 12;
         q.Ho = H; q.Wo = W; q.outH = 2 * H; q.outW = 2 * W; q.M = B * H * W;
+        q.pixel_shuffle = 1;
         q.out = x_hat; q.out_sx = 1; q.out_sy = q.outW; q.out_sc = (int64_t)q.outH * q.outW; q.out_sb = 3 * q.out_sc;
         q.epi = PC_EPI_CLAMP01;
         PCCHK(launch_conv(q, st));
@@ -753,7 +786,7 @@ extern "C" int pc_codec_finalize(pc_codec* c)
         PCCHK(load_wam(c, p + ".5", NCH, 8, 4, &g.w5));
         PCCHK(load_conv(c, p + ".6", NCH, NCH, 5, 1, &g.d6));
         PCCHK(load_gdn(c, p + ".7", NCH, &g.g7));
-        PCCHK(load_conv(c, p + ".8", NCH, 3, 5, 1, &g.d8));
+        PCCHK(load_deconv3_subpixel(c, p + ".8", NCH, &g.d8));
     }
     const int ha_c[6] = {MLAT, 320, 288, 256, 224, NCH};
     for (int j = 0; j < 5; ++j) PCCHK(load_conv(c, "h_a." + std::to_string(2 * j), ha_c[j], ha_c[j + 1], 3, 0, &c->ha[j]));
