@@ -117,6 +117,23 @@ __device__ __forceinline__ float fkey_inv(uint32_t k)
     return pc_bits2f((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
+// one histogram increment per DISTINCT bin of a wave: the scales of a slice share their exponent, so in the first radix pass nearly
+// all lanes hit the same two or three bins and per-lane LDS atomics serialise (65 us per call at Config 2 before this)
+__device__ __forceinline__ void hist_add_wave(uint32_t* hist, uint32_t bin, bool valid)
+{
+    const int lane = threadIdx.x & 63;
+    unsigned long long active = __ballot(valid);
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const uint32_t b = (uint32_t)__shfl((int)bin, leader);
+        const unsigned long long m = __ballot(valid && bin == b);
+        if (lane == leader) atomicAdd(&hist[b], (uint32_t)__popcll(m));
+        active &= ~m;
+    }
+}
+
+// EPT > 0: the image's n <= 1024*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per pass
+template <int EPT>
 __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
                                                            float* __restrict__ thr)
 {
@@ -126,6 +143,18 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
     const int64_t n = (int64_t)HW * C;
     const float* base = scale + (int64_t)b * HW * ld;
     auto elem = [&](int64_t e) -> float { const int64_t p = e / C; return base[p * ld + (e - p * C)]; };
+    constexpr int NK = EPT > 0 ? EPT : 1;
+    uint32_t keys[NK];
+    uint32_t nan_local = 0;
+    if (EPT > 0) {
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int64_t e = tid + 1024 * (int64_t)i;
+            float f = 0.0f;
+            if (e < n) { f = elem(e); if (f != f) nan_local++; }
+            keys[i] = fkey(f);
+        }
+    }
 
     const float rank = q * (float)(n - 1);
     const float lo_f = floorf(rank), hi_f = ceilf(rank);
@@ -139,20 +168,44 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
         for (int k = tid; k < 256; k += 1024) hist[k] = 0;
         __syncthreads();
         const uint32_t prefix = sh_prefix;
-        uint32_t nan_local = 0;
-        for (int64_t e = tid; e < n; e += 1024) {
-            const float f = elem(e);
-            if (pass == 0 && f != f) nan_local++;
-            const uint32_t k = fkey(f);
-            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        if (EPT > 0) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) {
+                const bool in = tid + 1024 * (int64_t)i < n;
+                const uint32_t bin = (keys[i] >> shift) & 255u;
+                if (pass == 0) hist_add_wave(hist, bin, in);                 // clustered digits: aggregate per wave
+                else if (in && (keys[i] & prefix_mask) == prefix) atomicAdd(&hist[bin], 1u);   // few survivors, spread digits
+            }
+        } else {
+            for (int64_t e = tid; e < n; e += 1024) {         // large images: plain LDS atomics measured faster than aggregation here
+                const float f = elem(e);
+                if (pass == 0 && f != f) nan_local++;
+                const uint32_t k = fkey(f);
+                if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            }
         }
         if (pass == 0 && nan_local) atomicAdd(&sh_nan, nan_local);
         __syncthreads();
-        if (tid == 0) {
-            uint32_t r = sh_rank, less = sh_less, d = 0;
-            for (; d < 256; ++d) { if (r < hist[d]) break; r -= hist[d]; less += hist[d]; }
-            sh_prefix = prefix | (d << shift);
-            sh_rank = r; sh_less = less; sh_eq = hist[d < 256 ? d : 255];
+        if (tid < 64) {
+            // digit d = first bin whose running count exceeds the remaining rank: one wave, 4 bins per lane + a wave prefix sum
+            const uint32_t r = sh_rank;
+            const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+            const uint32_t mine = h0 + h1 + h2 + h3;
+            uint32_t incl = mine;
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (tid >= off) incl += o; }
+            const uint32_t excl = incl - mine;
+            const unsigned long long hit = __ballot(r < incl);
+            if (hit) {
+                const int owner = __ffsll((long long)hit) - 1;
+                if (tid == owner) {
+                    uint32_t rr = r - excl, d = 4 * tid, hv = h0;
+                    if (rr >= h0) { rr -= h0; d++; hv = h1; if (rr >= h1) { rr -= h1; d++; hv = h2; if (rr >= h2) { rr -= h2; d++; hv = h3; } } }
+                    sh_prefix = prefix | (d << shift);
+                    sh_less += r - rr; sh_rank = rr; sh_eq = hv;
+                }
+            } else if (tid == 0) {                            // cannot happen for rank < n; keep the serial code's fallback
+                sh_prefix = prefix | (256u << shift); sh_less += incl; sh_rank = r - incl; sh_eq = hist[255];
+            }
         }
         __syncthreads();
         prefix_mask |= 0xffu << shift;
@@ -162,7 +215,12 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
     if (hi != lo && hi >= sh_less + sh_eq) {
         // next order statistic: the smallest key above key_lo
         uint32_t mn = 0xffffffffu;
-        for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = fkey(elem(e)); if (k > key_lo && k < mn) mn = k; }
+        if (EPT > 0) {
+#pragma unroll
+            for (int i = 0; i < NK; ++i) { const uint32_t k = keys[i]; if (tid + 1024 * (int64_t)i < n && k > key_lo && k < mn) mn = k; }
+        } else {
+            for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = fkey(elem(e)); if (k > key_lo && k < mn) mn = k; }
+        }
         for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
         if ((tid & 63) == 0) atomicMin(&sh_min, mn);
         __syncthreads();
@@ -320,7 +378,10 @@ int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, i
 int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t*, hipStream_t stream)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
-    hipLaunchKernelGGL(quantile_thr_kernel, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
+    const int64_t n = (int64_t)HW * C;
+    if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
+    else if (n <= 1024 * 32) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
+    else hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
     return PC_LAUNCH_CHECK();
 }
 size_t pc_quantile_work_bytes(int) { return 0; }

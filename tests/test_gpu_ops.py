@@ -165,7 +165,7 @@ def test_window_attention_bit_exact(case):
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), f"max abs diff {np.abs(got - want).max()}"
 
 
-@pytest.mark.parametrize("n_hw,pr", [(16, 0.5), (256, 0.05), (256, 5.0), (1536, 0.75), (4096, 9.99), (64, 2.0)])
+@pytest.mark.parametrize("n_hw,pr", [(16, 0.5), (256, 0.05), (256, 5.0), (1536, 0.75), (4096, 9.99), (64, 2.0), (1024, 1.0), (600, 0.1), (257, 3.0)])
 def test_quantile_threshold_bit_exact(n_hw, pr):
     L, check = _lib()
     rng = np.random.default_rng(n_hw)
