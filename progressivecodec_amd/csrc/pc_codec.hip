@@ -848,6 +848,9 @@ extern "C" int pc_codec_get_string(const pc_codec* c, int slice, int b, const ui
 // (numeric contract: no cross-image arithmetic), which tests/test_gpu_codec.py checks.
 namespace {
 
+#define PC_DEFAULT_LANES_ENC 1
+#define PC_DEFAULT_LANES_DEC 2
+
 struct ChainCtx {
     pc_codec* c;
     int B, h, w, HW;
@@ -876,10 +879,14 @@ int ensure_lanes(pc_codec* c, int n)
     return PC_OK;
 }
 
-int lane_count(const pc_codec* c, int B)
+int lane_count(const pc_codec* c, int B, bool decode)
 {
     static const int env = [] { const char* v = std::getenv("PC_LANES"); return v ? std::atoi(v) : 0; }();
-    int n = env > 0 ? env : 2;          // measured: 1 lane 93.0 ms, 2 lanes 91.6 ms, 4 lanes slower (Config 2)
+    static const int env_e = [] { const char* v = std::getenv("PC_LANES_ENC"); return v ? std::atoi(v) : 0; }();
+    static const int env_d = [] { const char* v = std::getenv("PC_LANES_DEC"); return v ? std::atoi(v) : 0; }();
+    // Config 2, round-1 final kernels (enc / dec ms per batch): lanes 1/1 35.9 / 36.4, 1/2 35.7 / 35.2, 2/2 37.1 / 36.0 -- the
+    // encoder's GEMMs fill the chip best undivided; in the decoder a second lane hides the other lane's host rANS round trips
+    int n = decode ? (env_d > 0 ? env_d : (env > 0 ? env : PC_DEFAULT_LANES_DEC)) : (env_e > 0 ? env_e : (env > 0 ? env : PC_DEFAULT_LANES_ENC));
     if (c->profile) n = 1;
     return std::max(1, std::min(n, std::min(B, 8)));
 }
@@ -1002,7 +1009,7 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
 int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* const* y_strings, const size_t* y_lens)
 {
     pc_codec* c = k.c;
-    const int nl = lane_count(c, k.B);
+    const int nl = lane_count(c, k.B, decode);
     if (nl == 1) {   // sequential on the caller's stream (also the profiling configuration)
         static const bool two = [] { const char* v = std::getenv("PC_DUAL_STREAM"); return !v || std::atoi(v) != 0; }();
         if (!two || c->profile) {
