@@ -184,6 +184,14 @@ PC_API int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strin
                                       const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
                                       const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream);
 
+/* forward_single_quality in eval mode (models/CHProg_cnn.py:1002-1198) -- SURVEY.md section 8(f) rank 2: the rate-estimation path
+ * behind test_epoch / valid_epoch (training/step.py:215-267).  Runs the encoder chain without entropy coding and returns the
+ * likelihood tensors: y_lik device [B][320 or 640][H/16][W/16] (640 when quality != 0), z_lik device [B][192][H/64][W/64],
+ * x_hat device [B][3][H][W] (identical to decompress(compress(x))), masks_out as in pc_codec_compress (may be NULL).
+ * Needs the entropy_bottleneck._matrix/_bias/_factor tensors in the state dict (PC_ERR_STATE otherwise). */
+PC_API int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol, float* x_hat,
+                            float* y_lik, float* z_lik, float* masks_out, void* stream);
+
 /* Measurement aid (bench.py roofline leg): while profiling is on, every launch of the MFMA convolution kernel made by
  * compress()/decompress() is bracketed by HIP events on the call's stream; _end returns the launch count, the summed
  * event time and the algorithmic FLOPs (2*M*N*K per launch, no padding counted). */

@@ -411,6 +411,64 @@ class RefCodec:
             T[f"e{i}"] = dict(mu=mu, scale=scale, mask=mask, idx=idx, sym=sym, y_hat=y_hat)
         return {"strings": [y_strings, z_strings], "shape": torch.Size([zh, zw]), "masks": masks}
 
+    # ---- likelihood path
+    def _gc_likelihood(self, values, scale_eff):
+        """GaussianConditional._likelihood (values = outputs - means, or outputs when no means are passed) + likelihood_lower_bound, entropy_models.py:626-659,
+        :578-582 (half * erfc(const * x), const = -(2 ** -0.5), all in float32).  Back-end "torch": torch.erfc as the reference;
+        "cdet": erfc in double on the float32 argument, rounded to float32 (what the HIP kernel does)."""
+        values = values.abs()
+        scales = torch.max(scale_eff, torch.tensor(self.scale_bound, dtype=torch.float32))       # lower_bound_scale
+        cst = torch.tensor(-(2 ** -0.5), dtype=torch.float32)
+        u, l = (0.5 - values) / scales, (-0.5 - values) / scales
+        if isinstance(self.ops, TorchOps):
+            up, low = 0.5 * torch.erfc(cst * u), 0.5 * torch.erfc(cst * l)
+        else:
+            from scipy.special import erfc
+            e = lambda t: torch.from_numpy(erfc((cst * t).numpy().astype(np.float64)).astype(np.float32))
+            up, low = 0.5 * e(u), 0.5 * e(l)
+        return torch.max(up - low, torch.tensor(1e-9, dtype=torch.float32))
+
+    def _eb_likelihood(self, z_hat):
+        """EntropyBottleneck._likelihood + likelihood_lower_bound on the dequantised hyper-latent, entropy_models.py:400-433,:446-479."""
+        B, C, h, w = z_hat.shape
+        v = z_hat.permute(1, 0, 2, 3).reshape(C, 1, -1)
+
+        def logits(x):
+            for i in range(5):
+                x = torch.matmul(F.softplus(self.sd[f"entropy_bottleneck._matrix{i}"]), x)
+                x = x + self.sd[f"entropy_bottleneck._bias{i}"]
+                if i < 4:
+                    x = x + torch.tanh(self.sd[f"entropy_bottleneck._factor{i}"]) * torch.tanh(x)
+            return x
+
+        lower, upper = logits(v - 0.5), logits(v + 0.5)
+        sign = -torch.sign(lower + upper)
+        lik = torch.abs(torch.sigmoid(sign * upper) - torch.sigmoid(sign * lower))
+        lik = torch.max(lik, torch.tensor(1e-9, dtype=torch.float32))
+        return lik.reshape(C, B, h, w).permute(1, 0, 2, 3).contiguous()
+
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std"):
+        """ChannelProgresssiveWACNN.forward_single_quality in eval mode, models/CHProg_cnn.py:1002-1198: the chain of compress()
+        (same mu / scale / mask / round / LRP per slice, :1033-1160) with likelihoods instead of entropy coding, then g_s."""
+        T = {}
+        self.compress(x, quality, mask_pol, taps=T)
+        med = self.medians.view(1, -1, 1, 1)
+        z_lik = self._eb_likelihood(T["z_sym"].float() + med)                       # compute_hyperprior :400
+        liks, y_hat = [], []
+        for i in range(NS0):                                                        # :1050
+            t = T[f"b{i}"]
+            outputs = t["sym"].float() + t["mu"]                                    # quantize(.., "dequantize", means), :137-139,:159-165
+            liks.append(self._gc_likelihood(outputs - t["mu"], t["scale"]))         # values = inputs - means (float32: not exactly sym)
+            y_hat.append(t["y_hat"])
+        if quality == 0:                                                            # :1063-1080
+            return {"x_hat": self.g_s(0, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}}
+        y_hat = []
+        for i in range(NS0):                                                        # :1150 (scale * block_mask, no means)
+            t = T[f"e{i}"]
+            liks.append(self._gc_likelihood(t["sym"].float(), t["scale"] * t["mask"]))
+            y_hat.append(t["y_hat"])
+        return {"x_hat": self.g_s(1, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}}
+
     def decompress(self, strings, shape, quality, mask_pol="point-based-std", taps=None):
         """ChannelProgresssiveWACNN.decompress, models/CHProg_cnn.py:849-999."""
         T = taps if taps is not None else {}

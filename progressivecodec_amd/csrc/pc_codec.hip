@@ -75,6 +75,7 @@ struct pc_codec {
     HsW hms[2], hss[2];
     Stack5W cc_mean[NS0], cc_scale[NS0], lrp[NS0], cc_mean_p[NS0], cc_scale_p[NS0], lrp_p[NS0];
     float* medians = nullptr;                    // [192] device
+    float* eb_net = nullptr;                     // [192][PC_EB_NET_FLOATS] device: density network of the EntropyBottleneck (forward path)
     float* scale_table = nullptr;                // [64] device
     int n_table = 0;
     float scale_bound = 0.11f;
@@ -662,10 +663,10 @@ extern "C" int pc_mask_quantile_threshold(const float* scale, int ld, int B, int
     return pc_quantile_thr_launch(scale, ld, B, HW, C, q, thr, nullptr, (hipStream_t)stream);
 }
 
-extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, const float* y, int ld_y,
-                                 const float* ybase, int ld_ybase, const float* thr, int mask_mode, int B, int HW,
-                                 const float* scale_table, int n_table, float scale_bound,
-                                 int32_t* sym, int32_t* idx, float* mask, float* yhat, int ld_yhat, void* stream)
+namespace {
+int prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, const float* y, int ld_y, const float* ybase, int ld_ybase,
+                const float* thr, int mask_mode, int B, int HW, const float* scale_table, int n_table, float scale_bound, int32_t* sym,
+                int32_t* idx, float* mask, float* yhat, int ld_yhat, float* lik, int64_t lik_sb, hipStream_t stream)
 {
     if (!scale || !mu || !y || !sym || !idx || !yhat || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
     pc_prep_params p;
@@ -675,7 +676,18 @@ extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* 
     p.ybase = ybase; p.ld_ybase = ld_ybase; p.thr = thr; p.mask_mode = mask_mode;
     p.table = scale_table; p.ntable = n_table; p.bound = scale_bound;
     p.sym = sym; p.idx = idx; p.mask = mask; p.yhat = yhat; p.ld_yhat = ld_yhat;
-    return pc_prep_enc_launch(p, (hipStream_t)stream);
+    p.lik = lik; p.lik_sb = lik_sb;
+    return pc_prep_enc_launch(p, stream);
+}
+}  // namespace
+
+extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, const float* y, int ld_y,
+                                 const float* ybase, int ld_ybase, const float* thr, int mask_mode, int B, int HW,
+                                 const float* scale_table, int n_table, float scale_bound,
+                                 int32_t* sym, int32_t* idx, float* mask, float* yhat, int ld_yhat, void* stream)
+{
+    return prep_encode(scale, ld_scale, mu, ld_mu, y, ld_y, ybase, ld_ybase, thr, mask_mode, B, HW, scale_table, n_table, scale_bound, sym,
+                       idx, mask, yhat, ld_yhat, nullptr, 0, (hipStream_t)stream);
 }
 
 extern "C" int pc_gc_prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW,
@@ -810,6 +822,28 @@ extern "C" int pc_codec_finalize(pc_codec* c)
         for (int i = 0; i < NCH; ++i) med[i] = reinterpret_cast<const float*>(q->data.data())[3 * i + 1];
         PCCHK(upload(c, med, &c->medians));
     }
+    {   // EntropyBottleneck density network for the likelihood path: softplus(_matrix_i), _bias_i, tanh(_factor_i)
+        // (entropy_models.py:400-418), filters (3,3,3,3); layout of pc_stages.hip: eb_logits
+        static const int F[6] = {1, 3, 3, 3, 3, 1};
+        std::vector<float> net((size_t)NCH * PC_EB_NET_FLOATS, 0.0f);
+        bool ok = true;
+        for (int i = 0; i < 5 && ok; ++i) {
+            const int fo = F[i + 1], fi = F[i];
+            const HostTensor* m = find(c, "entropy_bottleneck._matrix" + std::to_string(i), PC_F32, {NCH, fo, fi});
+            const HostTensor* b = find(c, "entropy_bottleneck._bias" + std::to_string(i), PC_F32, {NCH, fo, 1});
+            const HostTensor* f = i < 4 ? find(c, "entropy_bottleneck._factor" + std::to_string(i), PC_F32, {NCH, fo, 1}) : nullptr;
+            if (!m || !b || (i < 4 && !f)) { ok = false; break; }
+            const int base = i == 0 ? 0 : 9 + 15 * (i - 1);
+            for (int ch = 0; ch < NCH; ++ch) {
+                float* d = net.data() + (size_t)ch * PC_EB_NET_FLOATS + base;
+                const float* mm = reinterpret_cast<const float*>(m->data.data()) + (size_t)ch * fo * fi;
+                for (int e = 0; e < fo * fi; ++e) d[e] = mm[e] > 20.0f ? mm[e] : log1pf(expf(mm[e]));          // F.softplus
+                for (int e = 0; e < fo; ++e) d[fo * fi + e] = reinterpret_cast<const float*>(b->data.data())[(size_t)ch * fo + e];
+                if (f) for (int e = 0; e < fo; ++e) d[fo * fi + fo + e] = tanhf(reinterpret_cast<const float*>(f->data.data())[(size_t)ch * fo + e]);
+            }
+        }
+        if (ok) PCCHK(upload(c, net, &c->eb_net));          // absent in a state dict: pc_codec_forward returns PC_ERR_STATE
+    }
     {   // scale table from the module buffer (never recomputed), LowerBound from its buffer
         auto it = c->sd.find("gaussian_conditional.scale_table");
         if (it == c->sd.end() || it->second.dtype != PC_F32 || it->second.shape.size() != 1 || it->second.shape[0] < 2 || it->second.shape[0] > 64) return PC_ERR_MISSING;
@@ -860,6 +894,7 @@ struct ChainCtx {
     int mode; float q; bool enh;
     int step0, step1;                           // chain steps to run: [0,10) base, [10,20) enhancement
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
+    float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
 };
 
 template <typename T> inline T* img(T* p, int b0, size_t per_image) { return p ? p + (size_t)b0 * per_image : nullptr; }
@@ -957,17 +992,20 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     for (int step = k.step0; step < k.step1; ++step) {
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
+        // forward path: likelihood of slice `step` of image b at lik[((b * lik_nch) + 32 * step + c) * HW + p]
+        float* lik = k.lik ? k.lik + ((size_t)b0 * k.lik_nch + (size_t)32 * step) * pi : nullptr;
+        const int64_t lik_sb = (int64_t)k.lik_nch * (int64_t)pi;
         if (step < NS0) {                                                                // base slices, :729-764
-            PCCHK(pc_gc_prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT, nullptr, 0, nullptr, 0,
-                                    nb, k.HW, c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, nullptr,
-                                    img(k.yb, b0, pi * D0) + 32 * step, D0, sA));
+            PCCHK(prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT, nullptr, 0, nullptr, 0,
+                              nb, k.HW, c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, nullptr,
+                              img(k.yb, b0, pi * D0) + 32 * step, D0, lik, lik_sb, sA));
         } else {                                                                         // enhancement slices, :775-845
             const int i = step - NS0;
             float* m = k.masks ? k.masks + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE : nullptr;
-            PCCHK(pc_gc_prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT,
-                                    img(k.y, b0, pi * MLAT) + 32 * i, MLAT, k.thr + (size_t)i * k.B + b0, k.mode, nb, k.HW,
-                                    c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, m,
-                                    img(k.ye, b0, pi * D0) + 32 * i, D0, sA));
+            PCCHK(prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT,
+                              img(k.y, b0, pi * MLAT) + 32 * i, MLAT, k.thr + (size_t)i * k.B + b0, k.mode, nb, k.HW,
+                              c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, m,
+                              img(k.ye, b0, pi * D0) + 32 * i, D0, lik, lik_sb, sA));
         }
         PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
     }
@@ -1225,6 +1263,62 @@ extern "C" int pc_codec_get_level_string(const pc_codec* c, int level, int slice
     else if (slice < 2 * NS0 && c->res_level_coded[level]) s = &c->y_strings[((size_t)NS0 + (size_t)NS0 * level + (slice - NS0)) * c->res_B + b];
     else return PC_ERR_ARG;
     *data = s->data(); *len = s->size();
+    return PC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- forward (likelihood path)
+// forward_single_quality in eval mode (CHProg_cnn.py:1002-1198): the encoder chain without entropy
+// coding -- the likelihood of every quantised latent element under its Gaussian (entropy_models.py:626-659) comes out of the same
+// fused mask / index / quantise kernel, the hyper-latent's from the EntropyBottleneck density network (:400-433) -- followed by the
+// synthesis transform.  x_hat equals decompress(compress(x)) bit for bit (same y_hat); estimated bits = -sum(log2(likelihood)).
+extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol, float* x_hat,
+                                float* y_lik, float* z_lik, float* masks_out, void* stream)
+{
+    if (!c || !x || !x_hat || !y_lik || !z_lik || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
+    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (!c->finalized || !c->eb_net) return PC_ERR_STATE;
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    g_prof = c->profile ? c : nullptr;
+    const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
+    const size_t M = (size_t)B * HW;
+    const bool enh = quality != 0;                                                       // :1063 "if quality == 0 and force_enhanced is False"
+    c->last_B = B; c->last_h16 = h; c->last_w16 = w;
+
+    ChainCtx k;
+    std::memset(&k, 0, sizeof(k));
+    float *z, *z_hat;
+    int32_t* z_sym;
+    PCCHK(c->buf("y", M * MLAT, &k.y));
+    PCCHK(c->buf("z", (size_t)B * ZHW * NCH, &z));
+    PCCHK(c->buf("z_hat", (size_t)B * ZHW * NCH, &z_hat));
+    PCCHK(c->buf("z_sym", (size_t)B * ZHW * NCH, &z_sym));
+    PCCHK(c->buf("latent_means", M * MLAT, &k.lm));
+    PCCHK(c->buf("latent_scales", M * MLAT, &k.ls));
+    PCCHK(c->buf("yhat_base", M * D0, &k.yb));
+    PCCHK(c->buf("yhat_enh", M * D0, &k.ye));
+    PCCHK(c->buf("mu", M * SLICE * 2 * NS0, &k.mu));
+    PCCHK(c->buf("scale", M * SLICE * 2 * NS0, &k.scale));
+    PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
+    PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
+    PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
+    k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
+    k.lik = y_lik; k.lik_nch = enh ? 2 * D0 : D0;
+
+    PCCHK(g_a(c, st, x, B, H, W, k.y));                                                  // :1013
+    PCCHK(h_a(c, st, k.y, B, h, w, z));                                                  // compute_hyperprior :399
+    PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :401-403
+    PCCHK(pc_eb_likelihood_launch(z_sym, B, ZHW, NCH, c->medians, c->eb_net, z_lik, st));   // :400
+    PCCHK(hyper(c, st, z_hat, B, zh, zw, enh ? 1.0 : 0.0, k.lm, k.ls));                  // :404-417
+    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :1033-1061
+    if (enh) {
+        k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = 0;
+        k.mode = mask_mode_for(mask_pol, quality, &k.q);
+        k.masks = masks_out;
+        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :1089-1160
+    }
+    PCCHK(g_s(c, st, c->gs[enh ? 1 : 0], enh ? k.ye : k.yb, B, h, w, x_hat));            // :1065 / :1166-1170
     return PC_OK;
 }
 

@@ -92,6 +92,8 @@ struct pc_prep_params {
     int32_t* idx;                      // [B][C][HW]
     float* mask;                       // [B][C][HW] float 0/1 or null
     float* yhat; int ld_yhat;          // NHWC: float(sym) + mu
+    float* lik; int64_t lik_sb;        // optional (encoder): Gaussian likelihood of the coded symbol, element (b, c, p) at
+                                       // lik[b * lik_sb + c * HW + p]   (entropy_models.py:626-659)
 };
 int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream);
 int pc_prep_dec_index_launch(const pc_prep_params& p, hipStream_t stream);   // scale(+mask) -> idx (+mask)
@@ -105,5 +107,10 @@ int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* median
                        hipStream_t stream);
 int pc_eb_dequant_launch(const int32_t* sym, int B, int HW, int C, const float* medians, float* zhat,
                          hipStream_t stream);
+// EntropyBottleneck._likelihood of the dequantised hyper-latent (entropy_models.py:400-433): sym [B][C][HW] -> lik [B][C][HW];
+// net = PC_EB_NET_FLOATS floats per channel (softplus(matrix), bias, tanh(factor) of the 1-3-3-3-3-1 density network)
+#define PC_EB_NET_FLOATS 58
+int pc_eb_likelihood_launch(const int32_t* sym, int B, int HW, int C, const float* medians, const float* net, float* lik,
+                            hipStream_t stream);
 
 #endif

@@ -251,6 +251,23 @@ __device__ __forceinline__ int gc_index(float s, const float* table, int nt, flo
     return lo;
 }
 
+// GaussianConditional._likelihood of an already rounded value (entropy_models.py:626-643, :578-582), the way the reference's eval
+// path evaluates it (forward_single_quality, CHProg_cnn.py:1050,1150): values = |outputs - means| (base slices: the float32
+// expression (round(y-mu)+mu)-mu, not exactly the symbol) or |round(.)| (enhancement slices, no means), scales lower-bounded,
+// upper/lower = 0.5 * erfc(-(2**-0.5) * ((+-0.5 - values) / scales)) in float32, likelihood = max(upper - lower, 1e-9).
+// erfc is evaluated in double on its float32 argument and rounded (correctly rounded float erfc up to double rounding); not part
+// of the bitstream, so no cross-device contract is needed here: tolerance-tested against torch.erfc.
+__device__ __forceinline__ float gc_likelihood(float values, float s_eff)
+{
+    const float a = fabsf(values);
+    const float cst = -0.70710678118654752440f;
+    const float u = (0.5f - a) / s_eff, l = (-0.5f - a) / s_eff;
+    const float up = 0.5f * (float)erfc((double)(cst * u));
+    const float lo = 0.5f * (float)erfc((double)(cst * l));
+    const float lik = up - lo;
+    return lik > 1e-9f ? lik : 1e-9f;
+}
+
 template <int MODE>   // 0 = encoder (index+quantise+dequantise), 1 = decoder index only
 __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
 {
@@ -258,6 +275,7 @@ __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
     __shared__ int32_t t_sym[CC][TP + 1];
     __shared__ int32_t t_idx[CC][TP + 1];
     __shared__ float t_msk[CC][TP + 1];
+    __shared__ float t_lik[MODE == 0 ? CC : 1][TP + 1];
     __shared__ float s_table[64];
     const int b = blockIdx.y, p0 = blockIdx.x * TP, tid = threadIdx.x;
     if (tid < p.ntable && tid < 64) s_table[tid] = p.table[tid];
@@ -286,6 +304,10 @@ __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
             const int32_t sym = (int32_t)pc_roundevenf(v);
             t_sym[c][px] = sym;
             p.yhat[pix * p.ld_yhat + c] = (float)sym + mu;                 // CHProg_cnn.py:754-755,833-834
+            if (p.lik) {                                                   // lower_bound_scale, then _likelihood
+                const float values = (p.mask_mode == 0) ? ((float)sym + mu) - mu : (float)sym;
+                t_lik[c][px] = gc_likelihood(values, sm > p.bound ? sm : p.bound);
+            }
         }
     }
     __syncthreads();
@@ -298,6 +320,7 @@ __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
         p.idx[o] = t_idx[c][px];
         if (MODE == 0) p.sym[o] = t_sym[c][px];
         if (p.mask) p.mask[o] = t_msk[c][px];
+        if (MODE == 0 && p.lik) p.lik[(int64_t)b * p.lik_sb + (int64_t)c * p.HW + p0 + px] = t_lik[c][px];
     }
 }
 
@@ -372,6 +395,58 @@ int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, i
         hipLaunchKernelGGL((win_attention_kernel<4, 40>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
     else
         return PC_ERR_ARG;
+    return PC_LAUNCH_CHECK();
+}
+
+// EntropyBottleneck._logits_cumulative / _likelihood (entropy_models.py:400-433) on the dequantised hyper-latent.
+// net per channel: [sp0 3][b0 3][tf0 3] then 3 x {[sp 3x3][b 3][tf 3]} then [sp4 3][b4 1]; sp = softplus(matrix), tf = tanh(factor)
+__device__ __forceinline__ float eb_logits(const float* n, float x)
+{
+    float l[3], t[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { l[j] = n[j] * x + n[3 + j]; l[j] = l[j] + n[6 + j] * pc_tanhf(l[j]); }
+    n += 9;
+#pragma unroll
+    for (int layer = 0; layer < 3; ++layer) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float a = n[3 * j] * l[0];
+            a = a + n[3 * j + 1] * l[1];
+            a = a + n[3 * j + 2] * l[2];
+            a = a + n[9 + j];
+            t[j] = a + n[12 + j] * pc_tanhf(a);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) l[j] = t[j];
+        n += 15;
+    }
+    float o = n[0] * l[0];
+    o = o + n[1] * l[1];
+    o = o + n[2] * l[2];
+    return o + n[3];
+}
+
+__global__ void eb_likelihood_kernel(const int32_t* __restrict__ sym, int B, int HW, int C, const float* __restrict__ med,
+                                     const float* __restrict__ net, float* __restrict__ lik)
+{
+    const int64_t n = (int64_t)B * C * HW;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)((e / HW) % C);
+        const float v = (float)sym[e] + med[c];                       // quantize(.., "dequantize", medians), entropy_models.py:470-472
+        const float* w = net + (size_t)c * PC_EB_NET_FLOATS;
+        const float lower = eb_logits(w, v - 0.5f), upper = eb_logits(w, v + 0.5f);
+        const float sum = lower + upper;
+        const float sign = sum > 0.0f ? -1.0f : (sum < 0.0f ? 1.0f : 0.0f);          // -torch.sign(lower + upper)
+        const float l = fabsf(pc_sigmoidf(sign * upper) - pc_sigmoidf(sign * lower));
+        lik[e] = l > 1e-9f ? l : 1e-9f;
+    }
+}
+
+int pc_eb_likelihood_launch(const int32_t* sym, int B, int HW, int C, const float* med, const float* net, float* lik, hipStream_t stream)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    hipLaunchKernelGGL(eb_likelihood_kernel, dim3(blocks), dim3(256), 0, stream, sym, B, HW, C, med, net, lik);
     return PC_LAUNCH_CHECK();
 }
 

@@ -78,3 +78,30 @@ def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", de
     n_img = max(1, len(rows) // max(1, len(pr_list)))
     avg = lambda key, p: sum(r[key] for r in rows if r["quality"] == p) / n_img
     return ([avg("bpp", p) for p in pr_list], [avg("psnr", p) for p in pr_list], [avg("dec_time", p) for p in pr_list], rows)
+
+
+def estimate_rd(model, images, pr_list=None, mask_pol="point-based-std", device="cuda"):
+    """The likelihood-based RD table of test_epoch (training/step.py:215-267): per level, bpp = sum(log(likelihoods)) /
+    (-log(2) * pixels) (training/loss.py, the 'bpp' term) and PSNR of forward_single_quality's x_hat, averaged over the images.
+    No entropy coding runs.  Pixel count = the padded size, as the reference's criterion sees the padded tensor."""
+    import torch
+    import torch.nn.functional as F
+    pr_list = list(PR_LIST if pr_list is None else pr_list)
+    rows = []
+    with torch.no_grad():
+        for x in images:
+            x = x if x.dim() == 4 else x.unsqueeze(0)
+            x = x.to(device)
+            h, w = x.shape[2:]
+            pad, unpad = compute_padding(h, w, 64)
+            xp = F.pad(x, pad, mode="constant", value=0)
+            n_pix = xp.shape[0] * xp.shape[2] * xp.shape[3]
+            for p in pr_list:
+                out = model.forward_single_quality(xp, quality=p, mask_pol=mask_pol)
+                bpp = sum(torch.log(l.double()).sum().item() for l in out["likelihoods"].values()) / (-math.log(2) * n_pix)
+                x_hat = F.pad(out["x_hat"], unpad).clamp_(0, 1)
+                mse = torch.mean((x - x_hat) ** 2).item()
+                rows.append({"quality": p, "bpp": bpp, "psnr": -10.0 * math.log10(mse) if mse > 0 else float("inf")})
+    n_img = max(1, len(rows) // max(1, len(pr_list)))
+    avg = lambda key, p: sum(r[key] for r in rows if r["quality"] == p) / n_img
+    return [avg("bpp", p) for p in pr_list], [avg("psnr", p) for p in pr_list], rows

@@ -187,6 +187,36 @@ class ChannelProgresssiveWACNN:
         del keep
         return {"x_hat": x_hat}
 
+    # ------------------------------------------------------------------ likelihood (rate estimation) path
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std", force_enhanced=False, training=False):
+        """CHProg_cnn.py:1002-1198 in eval mode -- what test_epoch / valid_epoch call (training/step.py:215-267).
+        Returns {"x_hat", "likelihoods": {"y", "z"}, "masks"}: y [B, 320 or 640, H/16, W/16], z [B, 192, H/64, W/64]; estimated
+        bits = -sum(log2(likelihood)).  The auxiliary entries of the reference's dictionary (y_hat, mu, std ...) are not
+        returned.  Training-mode noise and force_enhanced are out of scope."""
+        import torch
+        if training or force_enhanced:
+            raise NotImplementedError("only the eval path of forward_single_quality is implemented (SURVEY.md section 8f)")
+        mask_pol = self.mask_policy if mask_pol is None else mask_pol
+        if mask_pol not in _MASK_POL:
+            raise NotImplementedError(f"mask policy {mask_pol!r}")
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("Invalid `inputs` size. Expected a [B,3,H,W] tensor.")
+        B, _, H, W = x.shape
+        if H % 64 or W % 64:
+            raise ValueError("H and W must be multiples of 64 (pad as training/step.py:318 does)")
+        x = x.to(self.device, torch.float32).contiguous()
+        h, w = H // 16, W // 16
+        nch = 640 if quality != 0 else 320
+        x_hat = torch.empty((B, 3, H, W), device=self.device, dtype=torch.float32)
+        y_lik = torch.empty((B, nch, h, w), device=self.device, dtype=torch.float32)
+        z_lik = torch.empty((B, 192, H // 64, W // 64), device=self.device, dtype=torch.float32)
+        masks = torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if quality != 0 else None
+        P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        check(lib().pc_codec_forward(self._h, P(x), B, H, W, float(quality), _MASK_POL[mask_pol], P(x_hat), P(y_lik), P(z_lik), P(masks),
+                                     self._stream()), "pc_codec_forward")
+        return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik},
+                "masks": [masks[i] for i in range(10)] if masks is not None else []}
+
     # ------------------------------------------------------------------ multi-level (shared base) coding
     def compress_levels(self, x, qualities, mask_pol=None):
         """compress() for a list of mask levels with the level-independent part (g_a, h_a, z, h_s, the ten base slices;

@@ -240,3 +240,71 @@ def test_harness_shared_base_gives_the_same_rd_table():
     b = compress_with_ac(gpu_codec(), imgs, PR_LIST, shared_base=True)
     assert a[0] == b[0] and a[1] == b[1]
     assert [(r["quality"], r["bpp"], r["psnr"]) for r in a[3]] == [(r["quality"], r["bpp"], r["psnr"]) for r in b[3]]
+
+
+# ------------------------------------------------------------------ likelihood path
+LIK_RTOL = 3e-7     # one float32 ulp: the HIP kernel and the oracle round a double erfc from different libms (ocml / scipy)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 11, "rand", 0), (2, 64, 64, 11, "rand", 0.5), (1, 128, 128, 12, "smooth", 2), (1, 64, 192, 13, "rand", 10)])
+def test_forward_single_quality_vs_oracle(case):
+    """pc_codec_forward against the oracle's restatement in the contract back-end: x_hat bit-exact (and equal to
+    decompress(compress(x))), likelihoods within one float32 ulp, estimated bits to 1e-7 relative."""
+    B, H, W, seed, kind, q = case
+    x = inputs(B, H, W, seed, kind)
+    net = gpu_codec()
+    out = net.forward_single_quality(x.cuda(), q, "point-based-std")
+    ref = oracle_codec("cdet").forward_single_quality(x, q)
+    ly, lz = out["likelihoods"]["y"].cpu(), out["likelihoods"]["z"].cpu()
+    ry, rz = ref["likelihoods"]["y"], ref["likelihoods"]["z"]
+    assert ly.shape == ry.shape and lz.shape == rz.shape
+    assert np.array_equal(out["x_hat"].cpu().numpy().view(np.uint32), ref["x_hat"].numpy().view(np.uint32))
+    rel = ((ly - ry).abs() / ry).max().item()
+    assert rel <= LIK_RTOL, rel
+    assert ((lz - rz).abs() / rz).max().item() <= 5e-6
+    bits = lambda t: float(-torch.log2(t.double()).sum())
+    assert abs(bits(ly) - bits(ry)) <= 1e-7 * bits(ry)
+    assert abs(bits(lz) - bits(rz)) <= 1e-6 * bits(rz)
+    d = net.compress(x.cuda(), q, "point-based-std")
+    xh = net.decompress(d["strings"], d["shape"], q, "point-based-std")["x_hat"]
+    assert torch.equal(out["x_hat"], xh)
+    for m, ms in zip(out["masks"], d["masks"]):
+        assert torch.equal(m, ms)
+
+
+def test_forward_single_quality_vs_reference_goldens():
+    """Against forward_single_quality of the real reference (tests/golden/forward.npz): estimated bits within 2e-3 relative
+    (a symbol that flips under float rounding moves its own likelihood), hyper-latent bits within 1e-5, PSNR within 2e-3 dB."""
+    import json
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward.npz"))
+    net = gpu_codec()
+    for m in json.loads(bytes(g["meta_json"]).decode()):
+        x = inputs(m["B"], m["H"], m["W"], m["seed"], m["kind"])
+        out = net.forward_single_quality(x.cuda(), m["quality"], "point-based-std")
+        ly, lz = out["likelihoods"]["y"].cpu(), out["likelihoods"]["z"].cpu()
+        assert list(ly.shape) == m["y_shape"] and list(lz.shape) == m["z_shape"]
+        by, bz = float(-torch.log2(ly.double()).sum()), float(-torch.log2(lz.double()).sum())
+        key = f"{m['case']}_q{m['quality']}"
+        sub = ly.flatten()[::53].numpy()
+        frac_close = float(np.mean(np.abs(sub - g[key + "|y_sub"]) <= 1e-5 * g[key + "|y_sub"]))
+        print(f"{key}: bits y {by:.3f} (ref {m['bits_y']:.3f}), z {bz:.3f} (ref {m['bits_z']:.3f}); {100 * frac_close:.1f} % of sampled likelihoods within 1e-5")
+        assert abs(by - m["bits_y"]) <= 2e-3 * m["bits_y"]
+        assert abs(bz - m["bits_z"]) <= 1e-5 * m["bits_z"]
+        assert frac_close >= 0.98
+        assert abs(psnr_of(x, out["x_hat"].cpu()) - m["psnr"]) <= PSNR_TOL_DB
+
+
+def test_estimated_rate_tracks_the_coded_rate():
+    """estimate_rd (test_epoch's table, step.py:215-267) against compress_with_ac on the same images: the likelihood-based bpp is
+    the model entropy at the continuous scale, the coder works from the 64-entry scale table (and the synthetic, untrained
+    weights fit the data loosely) -- the two agree within 6 %."""
+    from progressivecodec_amd.harness import compress_with_ac, estimate_rd
+    imgs = [inputs(1, 128, 128, 41), inputs(1, 64, 192, 42, "smooth")]
+    levels = [0, 0.5, 3, 10]
+    est_bpp, est_psnr, _ = estimate_rd(gpu_codec(), imgs, levels)
+    bpp, psnr, _, _ = compress_with_ac(gpu_codec(), imgs, levels, shared_base=True)
+    for e, c in zip(est_bpp, bpp):
+        assert 0.94 * e <= c <= 1.06 * e, (e, c)
+    assert np.allclose(est_psnr, psnr, atol=1e-9)
+    assert est_bpp == sorted(est_bpp)

@@ -143,3 +143,29 @@ def test_harness_padding_and_metrics():
     assert compute_padding(512, 768) == ((0, 0, 0, 0), (0, 0, 0, 0))
     assert compute_padding(100, 70)[0] == (29, 29, 14, 14)
     assert bpp_of([[[b"1234"], [b"12345678"]], [b"1234"]], 1, 4, 8) == 8 * 16 / 32
+
+
+# ------------------------------------------------------------------ likelihood path
+def _forward_golden():
+    import json
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "forward.npz"))
+    return g, json.loads(bytes(g["meta_json"]).decode())
+
+
+@pytest.mark.parametrize("idx", [0, 1, 5])
+def test_forward_single_quality_torch_backend_equals_reference(idx):
+    """The ATen back-end of the oracle reproduces the reference's forward_single_quality: likelihood subsamples bit for bit,
+    estimated bits to double rounding (fixtures: tests/golden/make_golden_forward.py)."""
+    from tests.util import inputs, oracle_codec
+    g, meta = _forward_golden()
+    m = meta[idx]
+    key = f"{m['case']}_q{m['quality']}"
+    x = inputs(m["B"], m["H"], m["W"], m["seed"], m["kind"])
+    out = oracle_codec("torch").forward_single_quality(x, m["quality"])
+    ly, lz = out["likelihoods"]["y"], out["likelihoods"]["z"]
+    assert list(ly.shape) == m["y_shape"] and list(lz.shape) == m["z_shape"]
+    assert np.array_equal(ly.flatten()[::53].numpy(), g[key + "|y_sub"])
+    assert np.allclose(lz.flatten()[::7].numpy(), g[key + "|z_sub"], rtol=2e-6, atol=0)
+    assert abs(float(-torch.log2(ly.double()).sum()) - m["bits_y"]) <= 1e-9 * m["bits_y"]
+    assert abs(float(-torch.log2(lz.double()).sum()) - m["bits_z"]) <= 1e-6 * m["bits_z"]
+    assert np.array_equal(out["x_hat"].flatten()[::53 * 7].numpy(), g[key + "|x_hat_sub"])

@@ -39,8 +39,15 @@ def main():
         net.decompress_levels([d["strings"] for d in ds], ds[0]["shape"], levels, "point-based-std")
         return sum(len(s) for d in ds for sl in d["strings"][0] for s in sl)
 
+    def estimate():                       # forward_single_quality per level (no entropy coding), test_epoch's path
+        n = 0.0
+        for q in levels:
+            o = net.forward_single_quality(x, q, "point-based-std")
+            n += float(-torch.log2(o["likelihoods"]["y"].double()).sum()) / 8
+        return int(n)
+
     out = {}
-    for name, fn in (("per_level_calls", per_level), ("shared_base", shared)):
+    for name, fn in (("per_level_calls", per_level), ("shared_base", shared), ("forward_single_quality_estimate", estimate)):
         nbytes = fn()
         torch.cuda.synchronize()
         t0 = time.time()
