@@ -133,7 +133,7 @@ PC_API int pc_gc_dequantize(const int32_t* sym, const float* mu, int ld_mu, int 
  * ------------------------------------------------------------------------------------- */
 typedef struct pc_codec pc_codec;
 
-enum { PC_MASK_POINT_BASED_STD = 0, PC_MASK_TWO_LEVELS = 1 };
+enum { PC_MASK_POINT_BASED_STD = 0, PC_MASK_TWO_LEVELS = 1, PC_MASK_THREE_LEVELS_STD = 2 };   /* layers/masking.py:205-247 */
 enum { PC_F32 = 0, PC_I32 = 1, PC_I64 = 2 };
 
 PC_API int pc_codec_create(pc_codec** out, int device);

@@ -330,6 +330,12 @@ class RefCodec:
             return torch.from_numpy(lo.mask_point_based_std(scale.numpy(), pr))
         if mask_pol == "two-levels":
             return torch.zeros_like(scale) if pr == 0 else torch.ones_like(scale)
+        if mask_pol == "three-levels-std":              # :229-247: quantile 0.8 == the point-based rule at pr = 2
+            if pr == 0:
+                return torch.zeros_like(scale)
+            if pr == 2:
+                return torch.ones_like(scale)
+            return torch.from_numpy(lo.mask_point_based_std(scale.numpy(), 2.0))
         raise NotImplementedError(mask_pol)
 
     def _encode(self, sym, idx, tables):                # entropy_models.py:226-235 (one stream per image, C,H,W order)

@@ -8,7 +8,7 @@ Layout (little endian):
 
     magic  "PCB1"                      4 B
     version                            u8   (= 1)
-    mask policy                        u8   (1 point-based-std, 2 two-levels: the PC_MASK_* codes of include/pcodec.h)
+    mask policy                        u8   (1 point-based-std, 2 two-levels, 3 three-levels-std)
     n_levels                           u16
     H, W  (original, un-padded size)   u32 u32
     zh, zw ("shape" of compress())     u16 u16
@@ -26,7 +26,7 @@ import struct
 
 MAGIC = b"PCB1"
 VERSION = 1
-MASK_POL = {"point-based-std": 1, "two-levels": 2}
+MASK_POL = {"point-based-std": 1, "two-levels": 2, "three-levels-std": 3}
 _MASK_POL_INV = {v: k for k, v in MASK_POL.items()}
 
 

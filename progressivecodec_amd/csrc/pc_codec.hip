@@ -570,6 +570,12 @@ int mask_mode_for(int mask_pol, double quality, float* q_out)
 {
     // layers/masking.py:205-228
     if (mask_pol == PC_MASK_TWO_LEVELS) return quality == 0 ? 3 : 2;
+    if (mask_pol == PC_MASK_THREE_LEVELS_STD) {       // :229-247: 0 -> zeros, 2 -> ones, anything else -> the top 20 % by scale
+        if (quality == 0) return 3;
+        if (quality == 2) return 2;
+        *q_out = (float)0.8;
+        return 1;
+    }
     if (quality >= 10) return 2;
     if (quality == 0) return 3;
     const double pr = quality * 0.1;          // :212
@@ -1135,7 +1141,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
                   float* const* masks_out, hipStream_t st)
 {
     if (!c || !x || !qualities || n_levels < 1 || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
-    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok()) return PC_ERR_STATE;
     if (c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
@@ -1275,7 +1281,7 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
                                 float* y_lik, float* z_lik, float* masks_out, void* stream)
 {
     if (!c || !x || !x_hat || !y_lik || !z_lik || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
-    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->eb_net) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
@@ -1333,7 +1339,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
                     hipStream_t st)
 {
     if (!c || !y_strings || !y_lens || !z_strings || !z_lens || !x_hat || !qualities || n_levels < 1 || B <= 0 || zh <= 0 || zw <= 0) return PC_ERR_ARG;
-    if (mask_pol != PC_MASK_POINT_BASED_STD && mask_pol != PC_MASK_TWO_LEVELS) return PC_ERR_ARG;
+    if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     g_prof = c->profile ? c : nullptr;

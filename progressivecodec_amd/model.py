@@ -17,7 +17,7 @@ from . import entropy
 from ._lib import check, lib
 from .arch import CodecConfig, param_spec
 
-_MASK_POL = {"point-based-std": 0, "two-levels": 1}
+_MASK_POL = {"point-based-std": 0, "two-levels": 1, "three-levels-std": 2}
 _DT = {"float32": 0, "int32": 1, "int64": 2}
 
 

@@ -308,3 +308,22 @@ def test_estimated_rate_tracks_the_coded_rate():
         assert 0.94 * e <= c <= 1.06 * e, (e, c)
     assert np.allclose(est_psnr, psnr, atol=1e-9)
     assert est_bpp == sorted(est_bpp)
+
+
+@pytest.mark.parametrize("pol,q", [("two-levels", 0), ("two-levels", 1), ("three-levels-std", 0), ("three-levels-std", 1), ("three-levels-std", 2)])
+def test_other_mask_policies_bit_exact_vs_oracle(pol, q):
+    """SURVEY section 8(f) rank 4 (the policies that need no learned or gradient map): layers/masking.py:227-247."""
+    x = inputs(2, 64, 128, 77)
+    net = gpu_codec()
+    out = net.compress(x.cuda(), q, pol)
+    orc = oracle_codec("cdet")
+    ref = orc.compress(x, q, pol)
+    assert out["strings"][1] == ref["strings"][1] and out["strings"][0] == ref["strings"][0]
+    for m, rm in zip(out["masks"], ref["masks"]):
+        assert np.array_equal(m.cpu().numpy(), rm.numpy())
+    if pol == "three-levels-std" and q == 1:
+        k = 32 * 4 * 8
+        assert all(abs(int(m[b].sum().item()) - 0.2 * k) <= 2 for m in out["masks"] for b in range(2))    # top 20 % by scale
+    dec = net.decompress(out["strings"], out["shape"], q, pol)["x_hat"].cpu()
+    rdec = orc.decompress(ref["strings"], ref["shape"], q, pol)["x_hat"]
+    assert np.array_equal(dec.numpy().view(np.uint32), rdec.numpy().view(np.uint32))
