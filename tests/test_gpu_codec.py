@@ -327,3 +327,36 @@ def test_other_mask_policies_bit_exact_vs_oracle(pol, q):
     dec = net.decompress(out["strings"], out["shape"], q, pol)["x_hat"].cpu()
     rdec = orc.decompress(ref["strings"], ref["shape"], q, pol)["x_hat"]
     assert np.array_equal(dec.numpy().view(np.uint32), rdec.numpy().view(np.uint32))
+
+
+def test_4k_frame_two_levels_properties():
+    """BASELINE Config 5 shape: one 3840x2160 frame (centre-padded to 3840x2176 as training/step.py:318 does), two mask levels
+    through the shared-base path.  Too large for the oracle in seconds, so size-independent properties: the multi-level result
+    equals the per-level calls, decode reproduces the encoder's reconstruction path (forward_single_quality's x_hat), masks hold
+    the requested share, byte counts grow with the level."""
+    from progressivecodec_amd.harness import compute_padding as cp
+    net = gpu_codec()
+    g = torch.Generator().manual_seed(5)
+    lo_res = torch.rand(1, 3, 270, 480, generator=g)
+    x = F.interpolate(lo_res, size=(2160, 3840), mode="bilinear", align_corners=False).clamp(0, 1)
+    pad, unpad = cp(2160, 3840)
+    xp = F.pad(x, pad).cuda()
+    assert tuple(xp.shape[2:]) == (2176, 3840)
+    levels = [0.5, 3]
+    datas = net.compress_levels(xp, levels, "point-based-std")
+    one = net.compress(xp, 3, "point-based-std")
+    assert datas[1]["strings"] == one["strings"]
+    outs = net.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], levels, "point-based-std")
+    fwd = net.forward_single_quality(xp, 3, "point-based-std")
+    assert torch.equal(outs[1]["x_hat"], fwd["x_hat"])
+    k = 32 * 136 * 240
+    for lv, share in zip(range(2), (0.05, 0.3)):
+        for m in datas[lv]["masks"]:
+            assert abs(int(m.sum().item()) - share * k) <= 8
+    nbytes = [sum(len(s[0]) for s in d["strings"][0]) for d in datas]
+    assert nbytes[0] < nbytes[1]
+    x_hat = F.pad(outs[1]["x_hat"], unpad)
+    assert tuple(x_hat.shape) == (1, 3, 2160, 3840) and 0.0 <= x_hat.min().item() and x_hat.max().item() <= 1.0
+    bits = float(-torch.log2(fwd["likelihoods"]["y"].double()).sum() - torch.log2(fwd["likelihoods"]["z"].double()).sum())
+    coded = 8 * (nbytes[1] + len(datas[1]["strings"][1][0]))
+    assert 0.9 * bits <= coded <= 1.1 * bits
