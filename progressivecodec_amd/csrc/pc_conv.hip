@@ -19,10 +19,12 @@
 // K -- so results are bit-identical for every tile shape, batch size and device, and equal
 // to oracle/pc_oracle.c:orc_conv_nhwc.
 //
-// Tiling: 256 threads = 4 waves (64 lanes); block tile BM x BN; K-chunk 16; each wave owns
-// TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); A/B chunks are register-staged
-// global->LDS with double buffering (one barrier per chunk); LDS images are k-major
-// ([k][m] / [k][n]) so every ds_read_b32 of an MFMA operand is bank-conflict-free.
+// Two kernels: conv_igemm_dma_kernel (further down; weight layout 1) serves every layer whose Cin is a multiple of 16 and
+// Cout > 4 -- all but two; conv_igemm_kernel (next; weight layout 0) is the plain form kept for the 3-channel input layer
+// (element gather from NCHW) and as the generic fallback behind pc_conv2d_nhwc: 256 threads = 4 waves, block tile BM x BN,
+// K-chunk 16, each wave owns TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); A/B chunks are register-staged
+// global->LDS with double buffering (one barrier per chunk); LDS images are k-major ([k][m] / [k][n]) so every ds_read_b32
+// of an MFMA operand is bank-conflict-free.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>

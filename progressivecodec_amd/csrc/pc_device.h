@@ -67,7 +67,7 @@ struct pc_conv_params {
     int ngroup;
     const float* g1_seg0; const float* g1_w; const float* g1_bias; float* g1_out;
     int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
-    int dbg;                                 // tuning ablations only (PC_CONV_DBG): 1 = skip MFMA, 2 = skip loader work
+    int dbg;                                 // tuning only (PC_CONV_DBG bits): 1 skip MFMAs, 2 skip DMA issue, 4 DMAs read the zero page, 64 stamps, 256 print occupancy
 };
 
 int pc_conv_launch(const pc_conv_params& p, hipStream_t stream);

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the MFMA conv kernel through the C ABI (pc_conv2d_nhwc) on representative layer shapes.
-usage: python tools/conv_tune.py [tile_cfg ...]     env PC_CONV_IMPL=1|2 selects the K-loop implementation."""
+usage: python tools/conv_tune.py [shape names ...] [plain-kernel tile_cfg ...]
+env (pc_conv.hip): PC_CONV_BK=32|64, PC_CONV_S=2|3|4 pick the LDS-DMA kernel's K-chunk / stage count; PC_CONV_DBG bits: 1 skip the
+MFMAs, 2 skip the DMA issue, 4 all DMAs read the zero page, 64 in-kernel stamps (printed below), 256 print occupancy;
+PC_TUNE_ITERS launches per timing (default 20)."""
 import ctypes as C
 import os
 import sys
