@@ -329,19 +329,32 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     unsigned long long t_entry = 0;
     if (STAMPS) t_entry = __builtin_amdgcn_s_memtime();
-    int phase = blockIdx.z;
+    // XCD-aware tile order (1-D grid).  Workgroups are handed to the 8 XCDs round-robin in dispatch order and every XCD has its
+    // own 4 MB L2.  With the plain (x = M tile, y = N tile) grid the N tiles / phases / groups that read the SAME activation tile
+    // ran thousands of workgroups apart and neighbouring M tiles (which share input rows through the taps) landed on different
+    // XCDs: PMC showed 3.7 GB (x2 by the gfx950 correction) fetched for the 0.4 GB input of the largest layer.  Here XCD x owns the
+    // contiguous band of M tiles [x*mpx, (x+1)*mpx) and walks it with (N tile, phase/group) fastest.
+    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
+    const int mpx = (MT + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int m_local = slot / (NT * NZ), nz = slot - m_local * (NT * NZ);
+    const int m_tile = xcd * mpx + m_local;
+    if (m_tile >= MT) return;                             // padding of the last band (whole workgroup, before any barrier)
+    const int zsel = nz / NT, n_tile = nz - zsel * NT;
+    int phase = zsel;
     const float* seg0_ptr = p.seg[0].ptr;
     const float* wbase = p.w;
     const float* bias = p.bias;
     float* outp = p.out;
-    if (p.ngroup == 2 && blockIdx.z == 1) { phase = 0; seg0_ptr = p.g1_seg0; wbase = p.g1_w; bias = p.g1_bias; outp = p.g1_out; }
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    if (p.ngroup == 2 && zsel == 1) { phase = 0; seg0_ptr = p.g1_seg0; wbase = p.g1_w; bias = p.g1_bias; outp = p.g1_out; }
+    if (p.ngroup == 2) phase = 0;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
     const int T = p.ntap[phase];
     const int HoWo = p.Ho * p.Wo;
     int chunks_per_tap = 0;
     for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
     const int nchunks = T * chunks_per_tap;
-    const int blk = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    const int blk = blockIdx.x;
 
     if (wave >= NMW) {
         // ------------------------------------------------------------------ loader waves
@@ -561,7 +574,8 @@ hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
     int tmax = 0;
     for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
     const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
-    dim3 grid((p.M + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ngroup == 2 ? 2 : p.nphase);
+    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
+    dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);       // 1-D: the kernel maps workgroup id -> (XCD band, M tile, N tile, phase/group)
     const bool stamps = (p.dbg & 64) != 0;
     auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true, SQ> : conv_igemm_dma_kernel<BK, S, WM, WN, false, SQ>;
     static bool attr_set[2] = {false, false};             // per instantiation: allow more than 64 KB of dynamic LDS
