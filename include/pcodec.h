@@ -156,6 +156,11 @@ PC_API int pc_codec_set_threads(pc_codec* c, int n_threads);
  * the next call; masks_out (device, [10][B][32][H/16][W/16], may be NULL) receives the "masks" entry. */
 PC_API int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol,
                              float* masks_out, void* stream);
+/* cust_map of compress() / decompress() (CHProg_cnn.py:686,849 -> layers/masking.py:171-194): device tensor NCHW
+ * [B][320][H/16][W/16]; when set, the NEXT compress / compress_levels / decompress / decompress_levels call thresholds this map
+ * (top quality*10 % per image and slice; quality >= 10 all, 0 none, whatever the mask policy) instead of the scale, then the
+ * pointer is cleared.  NULL clears it. */
+PC_API int pc_codec_set_cust_map(pc_codec* c, const float* cust_map);
 PC_API int pc_codec_num_slices(const pc_codec* c);
 /* string of y slice `slice` (0..n_slices-1) or of z (slice = -1) for image b */
 PC_API int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len);

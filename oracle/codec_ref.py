@@ -325,7 +325,9 @@ class RefCodec:
     def _indexes(self, scale):                          # entropy_models.py:661-666
         return torch.from_numpy(lo.build_indexes(scale.numpy(), self.scale_table.numpy(), self.scale_bound))
 
-    def _mask(self, scale, pr, mask_pol):               # layers/masking.py:163-228
+    def _mask(self, scale, pr, mask_pol, cust_map=None):   # layers/masking.py:163-247
+        if cust_map is not None:                        # :171-194: same quantile rule on the caller's map, whatever the policy
+            return torch.from_numpy(lo.mask_point_based_std(cust_map.contiguous().numpy(), pr))
         if mask_pol == "point-based-std":
             return torch.from_numpy(lo.mask_point_based_std(scale.numpy(), pr))
         if mask_pol == "two-levels":
@@ -367,7 +369,7 @@ class RefCodec:
         return [base[i]] + (enh[i - min(MAX_SUPPORT, i):i] if i > 0 else [])
 
     # ---- compress / decompress
-    def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None):
+    def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None, cust_map=None):
         """ChannelProgresssiveWACNN.compress, models/CHProg_cnn.py:686-847."""
         T = taps if taps is not None else {}
         y = self.g_a(x)                                                     # :692
@@ -398,6 +400,7 @@ class RefCodec:
         if quality <= 0:                                                    # :766-767
             return {"strings": [y_strings, z_strings], "shape": torch.Size([zh, zw]), "masks": masks}
         enh = []
+        cm = cust_map.chunk(NS0, 1) if cust_map is not None else None       # :721-722
         for i in range(NS0):                                                # :775-845
             y_slice = y_slices[NS0 + i] - y_slices[i]                       # delta_encode :780-781
             sup = self._enh_support(base, enh, i)
@@ -405,7 +408,7 @@ class RefCodec:
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
-            mask = self._mask(scale, quality, mask_pol)                     # :819-824
+            mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :819-824
             masks.append(mask)
             idx = self._indexes(scale * mask)                               # :828
             sym = torch.from_numpy(lo.quantize(((y_slice - mu) * mask).numpy()))   # :830
@@ -475,7 +478,7 @@ class RefCodec:
             y_hat.append(t["y_hat"])
         return {"x_hat": self.g_s(1, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}}
 
-    def decompress(self, strings, shape, quality, mask_pol="point-based-std", taps=None):
+    def decompress(self, strings, shape, quality, mask_pol="point-based-std", taps=None, cust_map=None):
         """ChannelProgresssiveWACNN.decompress, models/CHProg_cnn.py:849-999."""
         T = taps if taps is not None else {}
         y_strings, z_strings = strings
@@ -501,13 +504,14 @@ class RefCodec:
             T.update(y_hat=torch.cat(base, 1))
             return {"x_hat": x_hat}
         enh = []
+        cm = cust_map.chunk(NS0, 1) if cust_map is not None else None       # :850-851
         for i in range(NS0):                                                # :921-983
             sup = self._enh_support(base, enh, i)
             mean_support = torch.cat([lm[:, D0:]] + sup, 1)
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
-            mask = self._mask(scale, quality, mask_pol)                     # :960-965
+            mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :960-965
             idx = self._indexes(scale * mask)                               # :968
             sym = self._decode(y_strings[NS0 + i], idx, self.gc)
             y_hat = sym.float() + mu

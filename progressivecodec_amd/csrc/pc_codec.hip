@@ -75,6 +75,7 @@ struct pc_codec {
     HsW hms[2], hss[2];
     Stack5W cc_mean[NS0], cc_scale[NS0], lrp[NS0], cc_mean_p[NS0], cc_scale_p[NS0], lrp_p[NS0];
     float* medians = nullptr;                    // [192] device
+    const float* cust_map = nullptr;             // pc_codec_set_cust_map: consumed by the next compress / decompress call
     float* eb_net = nullptr;                     // [192][PC_EB_NET_FLOATS] device: density network of the EntropyBottleneck (forward path)
     float* scale_table = nullptr;                // [64] device
     int n_table = 0;
@@ -672,7 +673,8 @@ extern "C" int pc_mask_quantile_threshold(const float* scale, int ld, int B, int
 namespace {
 int prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, const float* y, int ld_y, const float* ybase, int ld_ybase,
                 const float* thr, int mask_mode, int B, int HW, const float* scale_table, int n_table, float scale_bound, int32_t* sym,
-                int32_t* idx, float* mask, float* yhat, int ld_yhat, float* lik, int64_t lik_sb, hipStream_t stream)
+                int32_t* idx, float* mask, float* yhat, int ld_yhat, float* lik, int64_t lik_sb, hipStream_t stream,
+                const float* mask_src = nullptr, int64_t mask_sb = 0)
 {
     if (!scale || !mu || !y || !sym || !idx || !yhat || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
     pc_prep_params p;
@@ -682,7 +684,7 @@ int prep_encode(const float* scale, int ld_scale, const float* mu, int ld_mu, co
     p.ybase = ybase; p.ld_ybase = ld_ybase; p.thr = thr; p.mask_mode = mask_mode;
     p.table = scale_table; p.ntable = n_table; p.bound = scale_bound;
     p.sym = sym; p.idx = idx; p.mask = mask; p.yhat = yhat; p.ld_yhat = ld_yhat;
-    p.lik = lik; p.lik_sb = lik_sb;
+    p.lik = lik; p.lik_sb = lik_sb; p.mask_src = mask_src; p.mask_sb = mask_sb;
     return pc_prep_enc_launch(p, stream);
 }
 }  // namespace
@@ -696,16 +698,26 @@ extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* 
                        idx, mask, yhat, ld_yhat, nullptr, 0, (hipStream_t)stream);
 }
 
-extern "C" int pc_gc_prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW,
-                                       const float* scale_table, int n_table, float scale_bound, int32_t* idx, float* mask,
-                                       void* stream)
+namespace {
+int prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW, const float* scale_table,
+                      int n_table, float scale_bound, int32_t* idx, float* mask, hipStream_t stream, const float* mask_src = nullptr,
+                      int64_t mask_sb = 0)
 {
     if (!scale || !idx || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
     pc_prep_params p;
     std::memset(&p, 0, sizeof(p));
     p.B = B; p.HW = HW; p.C = 32; p.scale = scale; p.ld_scale = ld_scale; p.thr = thr; p.mask_mode = mask_mode;
     p.table = scale_table; p.ntable = n_table; p.bound = scale_bound; p.idx = idx; p.mask = mask;
-    return pc_prep_dec_index_launch(p, (hipStream_t)stream);
+    p.mask_src = mask_src; p.mask_sb = mask_sb;
+    return pc_prep_dec_index_launch(p, stream);
+}
+}  // namespace
+
+extern "C" int pc_gc_prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW,
+                                       const float* scale_table, int n_table, float scale_bound, int32_t* idx, float* mask,
+                                       void* stream)
+{
+    return prep_decode_index(scale, ld_scale, thr, mask_mode, B, HW, scale_table, n_table, scale_bound, idx, mask, (hipStream_t)stream);
 }
 
 extern "C" int pc_gc_dequantize(const int32_t* sym, const float* mu, int ld_mu, int B, int HW, float* yhat, int ld_yhat, void* stream)
@@ -865,6 +877,13 @@ extern "C" int pc_codec_finalize(pc_codec* c)
     return PC_OK;
 }
 
+extern "C" int pc_codec_set_cust_map(pc_codec* c, const float* cust_map)
+{
+    if (!c) return PC_ERR_ARG;
+    c->cust_map = cust_map;
+    return PC_OK;
+}
+
 extern "C" int pc_codec_num_slices(const pc_codec* c) { return c ? c->res_slices : 0; }
 
 extern "C" int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len)
@@ -901,6 +920,7 @@ struct ChainCtx {
     int step0, step1;                           // chain steps to run: [0,10) base, [10,20) enhancement
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
+    const float* cust_map;                      // NCHW [B][320][HW]: enhancement masks threshold this map instead of the scale
 };
 
 template <typename T> inline T* img(T* p, int b0, size_t per_image) { return p ? p + (size_t)b0 * per_image : nullptr; }
@@ -932,6 +952,16 @@ int lane_count(const pc_codec* c, int B, bool decode)
     return std::max(1, std::min(n, std::min(B, 8)));
 }
 
+// per-image mask threshold of enhancement slice i (layers/masking.py:205-223): the (1 - pr/10) quantile of the slice's scale, or of
+// the caller's custom map when one was given (:171-194; its slice is a flat [32*HW] run per image, NCHW)
+int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, hipStream_t st)
+{
+    float* thr = k.thr + (size_t)i * k.B + b0;
+    if (!k.cust_map) return pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, thr, nullptr, st);
+    const float* m = k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * k.HW;
+    return pc_quantile_thr_launch(m, SLICE, nb, k.HW, SLICE, k.q, thr, nullptr, st, (int64_t)D0 * k.HW);
+}
+
 // mean / scale stacks (+ quantile threshold) of chain step `step` (0..9 base, 10..19 enhancement) for images [b0, b0+nb)
 int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hipStream_t sB, hipEvent_t eA, hipEvent_t eB,
                  const std::string& tag)
@@ -952,7 +982,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
             const int i = step - NS0, s = std::min(5, i);
             PCCHK(stack5_pair(c, sA, c->cc_mean_p[i], c->cc_scale_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}},
                               ls + D0, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
-            if (k.mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, k.thr + (size_t)i * k.B + b0, nullptr, sA));
+            if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sA));
         }
         return PC_OK;
     }
@@ -966,7 +996,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
         const int i = step - NS0, s = std::min(5, i);
         PCCHK(stack5(c, sA, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
         PCCHK(stack5(c, sB, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
-        if (k.mode == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, k.thr + (size_t)i * k.B + b0, nullptr, sB));   // :819-824
+        if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sB));   // :819-824
     }
     if (two) { HIPCHK(hipEventRecord(eB, sB)); HIPCHK(hipStreamWaitEvent(sA, eB, 0)); }
     return PC_OK;
@@ -1011,7 +1041,8 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
             PCCHK(prep_encode(k.scale + so, SLICE, k.mu + so, SLICE, img(k.y, b0, pi * MLAT) + 32 * step, MLAT,
                               img(k.y, b0, pi * MLAT) + 32 * i, MLAT, k.thr + (size_t)i * k.B + b0, k.mode, nb, k.HW,
                               c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, m,
-                              img(k.ye, b0, pi * D0) + 32 * i, D0, lik, lik_sb, sA));
+                              img(k.ye, b0, pi * D0) + 32 * i, D0, lik, lik_sb, sA,
+                              k.cust_map ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi));
         }
         PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
     }
@@ -1031,8 +1062,9 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         const bool e = step >= NS0;
         const int i = e ? step - NS0 : step;
-        PCCHK(pc_gc_prep_decode_index(k.scale + so, SLICE, e ? k.thr + (size_t)i * k.B + b0 : nullptr, e ? k.mode : 0, nb, k.HW,
-                                      c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA));
+        PCCHK(prep_decode_index(k.scale + so, SLICE, e ? k.thr + (size_t)i * k.B + b0 : nullptr, e ? k.mode : 0, nb, k.HW,
+                                c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA,
+                                (e && k.cust_map) ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi));
         HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
         HIPCHK(hipStreamSynchronize(sA));
         const auto td0 = std::chrono::steady_clock::now();
@@ -1170,6 +1202,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
     k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
+    k.cust_map = c->cust_map; c->cust_map = nullptr;
 
     const size_t n_half = (size_t)NS0 * M * SLICE, n_z = (size_t)B * ZHW * NCH;      // symbols of one pass / of z
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
@@ -1220,7 +1253,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     for (int l = 0; l < n_levels; ++l) {
         if (qualities[l] <= 0) continue;                                                 // base only: nothing level-specific to code
         k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
-        k.mode = mask_mode_for(mask_pol, qualities[l], &k.q);
+        k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);   // a custom map overrides the policy
         k.masks = masks_out ? masks_out[l] : nullptr;
         PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :775-845
         const int bufsel = n_coded & 1;
@@ -1365,6 +1398,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
     k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
+    k.cust_map = c->cust_map; c->cust_map = nullptr;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
     PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
     const int nt = c->n_threads == 1 ? 1 : 0;
@@ -1388,7 +1422,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
             continue;
         }
         k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
-        k.mode = mask_mode_for(mask_pol, qualities[l], &k.q);
+        k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);
         PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :930-983
         PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990
     }

@@ -86,6 +86,8 @@ struct pc_prep_params {
     const float* y; int ld_y;          // encoder: latent slice
     const float* ybase; int ld_ybase;  // encoder, delta_encode: base slice to subtract (or null)
     const float* thr;                  // per-image mask threshold (null: no mask; enhancement only)
+    const float* mask_src; int64_t mask_sb;   // optional: threshold this map instead of `scale` (cust_map, masking.py:171-194):
+                                       // element (b, c, p) at mask_src[b * mask_sb + c * HW + p]
     int mask_mode;                     // 0 none, 1 threshold compare, 2 all ones, 3 all zeros
     const float* table; int ntable; float bound;
     int32_t* sym;                      // [B][C][HW]  (C,H,W raster order = rANS order)
@@ -100,7 +102,7 @@ int pc_prep_dec_index_launch(const pc_prep_params& p, hipStream_t stream);   // 
 int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream); // sym + mu -> yhat
 
 int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work,
-                           hipStream_t stream);
+                           hipStream_t stream, int64_t batch_stride = 0);   // batch_stride 0: HW * ld
 size_t pc_quantile_work_bytes(int B);
 
 int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* medians, int32_t* sym, float* zhat,

@@ -135,13 +135,13 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* hist, uint32_t bin, bool
 // EPT > 0: the image's n <= 1024*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per pass
 template <int EPT>
 __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
-                                                           float* __restrict__ thr)
+                                                           float* __restrict__ thr, int64_t sb)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_prefix, sh_rank, sh_less, sh_eq, sh_nan, sh_min;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t n = (int64_t)HW * C;
-    const float* base = scale + (int64_t)b * HW * ld;
+    const float* base = scale + (int64_t)b * sb;
     auto elem = [&](int64_t e) -> float { const int64_t p = e / C; return base[p * ld + (e - p * C)]; };
     constexpr int NK = EPT > 0 ? EPT : 1;
     uint32_t keys[NK];
@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
         const int64_t pix = (int64_t)b * p.HW + p0 + px;
         const float s = p.scale[pix * p.ld_scale + c];
         float m = 1.0f;
-        if (p.mask_mode == 1) m = (s >= thr) ? 1.0f : 0.0f;
+        if (p.mask_mode == 1) {
+            const float mv = p.mask_src ? p.mask_src[(int64_t)b * p.mask_sb + (int64_t)c * p.HW + p0 + px] : s;
+            m = (mv >= thr) ? 1.0f : 0.0f;
+        }
         else if (p.mask_mode == 3) m = 0.0f;
         const float sm = (p.mask_mode == 0) ? s : s * m;
         t_idx[c][px] = gc_index(sm, s_table, p.ntable, p.bound);
@@ -450,13 +453,14 @@ int pc_eb_likelihood_launch(const int32_t* sym, int B, int HW, int C, const floa
     return PC_LAUNCH_CHECK();
 }
 
-int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t*, hipStream_t stream)
+int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t*, hipStream_t stream, int64_t sb)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
+    if (sb == 0) sb = (int64_t)HW * ld;
     const int64_t n = (int64_t)HW * C;
-    if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
-    else if (n <= 1024 * 32) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
-    else hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr);
+    if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
+    else if (n <= 1024 * 32) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
+    else hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     return PC_LAUNCH_CHECK();
 }
 size_t pc_quantile_work_bytes(int) { return 0; }

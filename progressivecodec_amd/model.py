@@ -123,11 +123,22 @@ class ChannelProgresssiveWACNN:
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _set_cust_map(self, cust_map, B, h, w):
+        """cust_map: [B, 320, H/16, W/16] importance map whose per-slice quantile replaces the scale's (layers/masking.py:171-194).
+        Returns the device tensor (keep it alive until the call has been issued)."""
+        import torch
+        if cust_map is None:
+            check(lib().pc_codec_set_cust_map(self._h, None), "pc_codec_set_cust_map")
+            return None
+        if tuple(cust_map.shape) != (B, 320, h, w):
+            raise ValueError(f"cust_map must be [B, 320, H/16, W/16] = {(B, 320, h, w)}, got {tuple(cust_map.shape)}")
+        cm = cust_map.to(self.device, torch.float32).contiguous()
+        check(lib().pc_codec_set_cust_map(self._h, C.c_void_p(cm.data_ptr())), "pc_codec_set_cust_map")
+        return cm
+
     def compress(self, x, quality=0.0, mask_pol=None, cust_map=None):
         """CHProg_cnn.py:686-847.  Returns {"strings": [y_strings, z_strings], "shape", "masks"}."""
         import torch
-        if cust_map is not None:
-            raise NotImplementedError("cust_map masks are out of scope (SURVEY.md section 8f)")
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in _MASK_POL:
             raise NotImplementedError(f"mask policy {mask_pol!r}")
@@ -142,6 +153,7 @@ class ChannelProgresssiveWACNN:
         h, w = H // 16, W // 16
         n_enh = 0 if quality <= 0 else 10
         masks = torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if n_enh else None
+        cm = self._set_cust_map(cust_map if quality > 0 else None, B, h, w)      # CHProg_cnn.py:721-722
         check(lib().pc_codec_compress(self._h, C.c_void_p(x.data_ptr()), B, H, W, float(quality), _MASK_POL[mask_pol],
                                       C.c_void_p(masks.data_ptr()) if masks is not None else None, self._stream()),
               "pc_codec_compress")
@@ -160,8 +172,6 @@ class ChannelProgresssiveWACNN:
     def decompress(self, strings, shape, quality, mask_pol=None, cust_map=None):
         """CHProg_cnn.py:849-999.  Returns {"x_hat": Tensor[B,3,H,W] in [0,1]}."""
         import torch
-        if cust_map is not None:
-            raise NotImplementedError("cust_map masks are out of scope (SURVEY.md section 8f)")
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in _MASK_POL:
             raise NotImplementedError(f"mask policy {mask_pol!r}")
@@ -182,6 +192,7 @@ class ChannelProgresssiveWACNN:
         zp = (C.c_char_p * B)(*z_strings)
         zl = (C.c_size_t * B)(*[len(s) for s in z_strings])
         x_hat = torch.empty((B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
+        cm = self._set_cust_map(cust_map if quality > 0 else None, B, 4 * zh, 4 * zw)                     # CHProg_cnn.py:850-851
         check(lib().pc_codec_decompress(self._h, yp, yl, ns, zp, zl, B, zh, zw, float(quality), _MASK_POL[mask_pol],
                                         C.c_void_p(x_hat.data_ptr()), self._stream()), "pc_codec_decompress")
         del keep

@@ -360,3 +360,31 @@ def test_4k_frame_two_levels_properties():
     bits = float(-torch.log2(fwd["likelihoods"]["y"].double()).sum() - torch.log2(fwd["likelihoods"]["z"].double()).sum())
     coded = 8 * (nbytes[1] + len(datas[1]["strings"][1][0]))
     assert 0.9 * bits <= coded <= 1.1 * bits
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_cust_map_bit_exact_vs_oracle_and_reference_goldens(idx):
+    """compress()/decompress() with cust_map (CHProg_cnn.py:721-722,823 -> masking.py:171-194): GPU == oracle (contract back-end) on
+    every string, mask and x_hat; mask popcounts equal the reference's, bpp / PSNR within the tolerances of the other goldens."""
+    import json
+    import os
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cust_map.json")))[idx]
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    cm = torch.rand(c["B"], 320, c["H"] // 16, c["W"] // 16, generator=torch.Generator().manual_seed(c["seed"] + 1000))
+    net = gpu_codec()
+    out = net.compress(x.cuda(), c["quality"], c["mask_pol"], cust_map=cm)
+    orc = oracle_codec("cdet")
+    ref = orc.compress(x, c["quality"], c["mask_pol"], cust_map=cm)
+    assert out["strings"][0] == ref["strings"][0] and out["strings"][1] == ref["strings"][1]
+    for m, rm in zip(out["masks"], ref["masks"]):
+        assert np.array_equal(m.cpu().numpy(), rm.numpy())
+    assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    dec = net.decompress(out["strings"], out["shape"], c["quality"], c["mask_pol"], cust_map=cm)["x_hat"].cpu()
+    rdec = orc.decompress(ref["strings"], ref["shape"], c["quality"], c["mask_pol"], cust_map=cm)["x_hat"]
+    assert np.array_equal(dec.numpy().view(np.uint32), rdec.numpy().view(np.uint32))
+    assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) <= BPP_TOL * max(1.0, c["bpp"])
+    assert abs(psnr_of(x, dec.clamp(0, 1)) - c["psnr"]) <= PSNR_TOL_DB
+    # without the map the masks differ (the map really is what was thresholded)
+    if 0 < c["quality"] < 10 and c["mask_pol"] == "point-based-std":
+        plain = net.compress(x.cuda(), c["quality"], c["mask_pol"])
+        assert any(not torch.equal(a, b) for a, b in zip(plain["masks"], out["masks"]))

@@ -169,3 +169,29 @@ def test_forward_single_quality_torch_backend_equals_reference(idx):
     assert abs(float(-torch.log2(ly.double()).sum()) - m["bits_y"]) <= 1e-9 * m["bits_y"]
     assert abs(float(-torch.log2(lz.double()).sum()) - m["bits_z"]) <= 1e-6 * m["bits_z"]
     assert np.array_equal(out["x_hat"].flatten()[::53 * 7].numpy(), g[key + "|x_hat_sub"])
+
+
+# ------------------------------------------------------------------ cust_map masks
+def _cust_cases():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "cust_map.json")))
+
+
+def cust_map_of(c):
+    return torch.rand(c["B"], 320, c["H"] // 16, c["W"] // 16, generator=torch.Generator().manual_seed(c["seed"] + 1000))
+
+
+@pytest.mark.parametrize("idx", [0, 2])
+def test_cust_map_torch_backend_equals_reference(idx):
+    """compress()/decompress() with a caller-supplied importance map: every string, mask popcount and the x_hat hash of the
+    reference (tests/golden/make_golden_custmap.py) are reproduced by the oracle's ATen back-end."""
+    c = _cust_cases()[idx]
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    cm = cust_map_of(c)
+    orc = oracle_codec("torch")
+    out = orc.compress(x, c["quality"], c["mask_pol"], cust_map=cm)
+    ys, zs = out["strings"]
+    assert [[hashlib.sha256(s).hexdigest() for s in sl] for sl in ys] == c["y_sha"]
+    assert [hashlib.sha256(s).hexdigest() for s in zs] == c["z_sha"]
+    assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    dec = orc.decompress(out["strings"], out["shape"], c["quality"], c["mask_pol"], cust_map=cm)["x_hat"].clamp(0, 1)
+    assert hashlib.sha256(dec.numpy().tobytes()).hexdigest() == c["x_hat_sha"]
