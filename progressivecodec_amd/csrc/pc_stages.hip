@@ -132,17 +132,25 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* hist, uint32_t bin, bool
     }
 }
 
-// EPT > 0: the image's n <= 1024*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per pass
-template <int EPT>
-__global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
-                                                           float* __restrict__ thr, int64_t sb)
+// One workgroup selects the order statistics lo = floor(q*(n_total-1)) and lo+1 of one image and writes the interpolated threshold.
+// EPT > 0: the n_scan <= 1024*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per
+// pass.  CAND: the keys come from a candidate list (multi-block path below) that holds every element of the histogram bins
+// containing the two ranks; less0 elements of the image lie below those bins, nan0 NaNs were seen by the histogram pass.
+template <int EPT, bool CAND>
+__device__ __forceinline__ void quantile_block(const float* __restrict__ base, int ld, int C, const uint32_t* __restrict__ cand,
+                                               int64_t n_scan, int64_t n_total, uint32_t less0, uint32_t nan0, float q, float* out)
 {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t sh_prefix, sh_rank, sh_less, sh_eq, sh_nan, sh_min;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t n = (int64_t)HW * C;
-    const float* base = scale + (int64_t)b * sb;
-    auto elem = [&](int64_t e) -> float { const int64_t p = e / C; return base[p * ld + (e - p * C)]; };
+    const int tid = threadIdx.x;
+    const int64_t n = n_scan;
+    auto key_at = [&](int64_t e, uint32_t& nan_acc) -> uint32_t {
+        if (CAND) return cand[e];
+        const int64_t p = e / C;
+        const float f = base[p * ld + (e - p * C)];
+        if (f != f) nan_acc++;
+        return fkey(f);
+    };
     constexpr int NK = EPT > 0 ? EPT : 1;
     uint32_t keys[NK];
     uint32_t nan_local = 0;
@@ -150,18 +158,16 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
             const int64_t e = tid + 1024 * (int64_t)i;
-            float f = 0.0f;
-            if (e < n) { f = elem(e); if (f != f) nan_local++; }
-            keys[i] = fkey(f);
+            keys[i] = e < n ? key_at(e, nan_local) : 0u;
         }
     }
 
-    const float rank = q * (float)(n - 1);
+    const float rank = q * (float)(n_total - 1);
     const float lo_f = floorf(rank), hi_f = ceilf(rank);
     const uint32_t lo = (uint32_t)lo_f, hi = (uint32_t)hi_f;
     const float w = rank - lo_f;
 
-    if (tid == 0) { sh_prefix = 0; sh_rank = lo; sh_less = 0; sh_nan = 0; sh_min = 0xffffffffu; }
+    if (tid == 0) { sh_prefix = 0; sh_rank = lo - less0; sh_less = less0; sh_nan = nan0; sh_min = 0xffffffffu; }
     uint32_t prefix_mask = 0;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
@@ -177,12 +183,12 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
                 else if (in && (keys[i] & prefix_mask) == prefix) atomicAdd(&hist[bin], 1u);   // few survivors, spread digits
             }
         } else {
+            uint32_t nan_pass = 0;
             for (int64_t e = tid; e < n; e += 1024) {         // large images: plain LDS atomics measured faster than aggregation here
-                const float f = elem(e);
-                if (pass == 0 && f != f) nan_local++;
-                const uint32_t k = fkey(f);
+                const uint32_t k = key_at(e, nan_pass);
                 if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
             }
+            if (pass == 0) nan_local = nan_pass;
         }
         if (pass == 0 && nan_local) atomicAdd(&sh_nan, nan_local);
         __syncthreads();
@@ -214,12 +220,12 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
     uint32_t key_hi = key_lo;
     if (hi != lo && hi >= sh_less + sh_eq) {
         // next order statistic: the smallest key above key_lo
-        uint32_t mn = 0xffffffffu;
+        uint32_t mn = 0xffffffffu, dummy = 0;
         if (EPT > 0) {
 #pragma unroll
             for (int i = 0; i < NK; ++i) { const uint32_t k = keys[i]; if (tid + 1024 * (int64_t)i < n && k > key_lo && k < mn) mn = k; }
         } else {
-            for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = fkey(elem(e)); if (k > key_lo && k < mn) mn = k; }
+            for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = key_at(e, dummy); if (k > key_lo && k < mn) mn = k; }
         }
         for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
         if ((tid & 63) == 0) atomicMin(&sh_min, mn);
@@ -234,8 +240,127 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
             const float d = bb - a;
             r = (fabsf(w) < 0.5f) ? fmaf(w, d, a) : fmaf(-d, 1.0f - w, bb);
         }
-        thr[b] = r;
+        *out = r;
     }
+}
+
+template <int EPT>
+__global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
+                                                           float* __restrict__ thr, int64_t sb)
+{
+    const int b = blockIdx.x;
+    const int64_t n = (int64_t)HW * C;
+    quantile_block<EPT, false>(scale + (int64_t)b * sb, ld, C, nullptr, n, n, 0u, 0u, q, thr + b);
+}
+
+// ---- multi-block path for large images (n > 32768): the single-workgroup kernel above reads an image five times from one CU.
+// Here (1) G workgroups per image build a 4096-bin histogram of the keys' top 12 bits, (2) one workgroup finds the bins holding the
+// two ranks, (3) G workgroups collect the keys of those bins (a few percent of the image) into a candidate list, (4) one workgroup
+// runs the exact register-resident select on the candidates.  Two passes over the data instead of five, spread over the chip.
+// work (uint32 per image, stride PC_QW_STRIDE): [0,4096) histogram, then nan count, candidate count, bin_lo, bin_hi, less, pad[3],
+// then up to PC_QW_CAP candidate keys; more candidates than that (degenerate data) fall back to the generic select in step 4.
+#define PC_QW_BINS 4096
+#define PC_QW_CAP 32768
+#define PC_QW_HDR (PC_QW_BINS + 8)
+#define PC_QW_STRIDE (PC_QW_HDR + PC_QW_CAP)
+
+__global__ void quantile_zero_kernel(uint32_t* __restrict__ work)
+{
+    uint32_t* w = work + (size_t)blockIdx.x * PC_QW_STRIDE;
+    for (int k = threadIdx.x; k < PC_QW_HDR; k += blockDim.x) w[k] = 0;
+}
+
+__global__ __launch_bounds__(1024) void quantile_hist_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
+                                                            uint32_t* __restrict__ work)
+{
+    __shared__ uint32_t h[PC_QW_BINS];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    for (int k = tid; k < PC_QW_BINS; k += 1024) h[k] = 0;
+    __syncthreads();
+    const int64_t n = (int64_t)HW * C;
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
+    const float* base = scale + (int64_t)b * sb;
+    uint32_t nanl = 0;
+    for (int64_t e = e0 + tid; e < e1; e += 1024) {
+        const int64_t p = e / C;
+        const float f = base[p * ld + (e - p * C)];
+        if (f != f) nanl++;
+        atomicAdd(&h[fkey(f) >> 20], 1u);
+    }
+    __syncthreads();
+    uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+    for (int k = tid; k < PC_QW_BINS; k += 1024) if (h[k]) atomicAdd(&w[k], h[k]);
+    if (nanl) atomicAdd(&w[PC_QW_BINS], nanl);
+}
+
+__global__ __launch_bounds__(256) void quantile_pick_kernel(int64_t n, float q, uint32_t* __restrict__ work)
+{
+    __shared__ uint32_t part[256];
+    uint32_t* w = work + (size_t)blockIdx.x * PC_QW_STRIDE;
+    const int tid = threadIdx.x;
+    uint32_t mine = 0;
+    for (int k = 0; k < 16; ++k) mine += w[16 * tid + k];
+    part[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        const float rank = q * (float)(n - 1);
+        const uint32_t lo = (uint32_t)floorf(rank), hi = (uint32_t)ceilf(rank);
+        uint32_t acc = 0, bin_lo = PC_QW_BINS - 1, bin_hi = PC_QW_BINS - 1, less = 0;
+        bool got_lo = false, got_hi = false;
+        for (int t = 0; t < 256 && !got_hi; ++t) {
+            if (acc + part[t] <= lo && (got_lo || acc + part[t] <= hi)) { acc += part[t]; continue; }
+            for (int k = 0; k < 16 && !got_hi; ++k) {
+                const uint32_t c = w[16 * t + k];
+                if (!got_lo && lo < acc + c) { got_lo = true; bin_lo = 16 * t + k; less = acc; }
+                if (got_lo && hi < acc + c) { got_hi = true; bin_hi = 16 * t + k; }
+                acc += c;
+            }
+        }
+        w[PC_QW_BINS + 2] = bin_lo; w[PC_QW_BINS + 3] = bin_hi; w[PC_QW_BINS + 4] = less;
+    }
+}
+
+__global__ __launch_bounds__(1024) void quantile_collect_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
+                                                               uint32_t* __restrict__ work)
+{
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+    const uint32_t bin_lo = w[PC_QW_BINS + 2], bin_hi = w[PC_QW_BINS + 3];
+    uint32_t* cand = w + PC_QW_HDR;
+    const int64_t n = (int64_t)HW * C;
+    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
+    const float* base = scale + (int64_t)b * sb;
+    for (int64_t eb = e0; eb < e1; eb += 1024) {              // uniform trip count: the ballot needs the whole wave
+        const int64_t e = eb + tid;
+        uint32_t k = 0;
+        bool take = false;
+        if (e < e1) {
+            const int64_t p = e / C;
+            k = fkey(base[p * ld + (e - p * C)]);
+            const uint32_t bin = k >> 20;
+            take = bin == bin_lo || bin == bin_hi;
+        }
+        const unsigned long long m = __ballot(take);
+        if (m) {
+            uint32_t start = 0;
+            const int leader = __ffsll((long long)m) - 1;
+            if (lane == leader) start = atomicAdd(&w[PC_QW_BINS + 1], (uint32_t)__popcll(m));
+            start = (uint32_t)__shfl((int)start, leader);
+            const uint32_t idx = start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (take && idx < PC_QW_CAP) cand[idx] = k;
+        }
+    }
+}
+
+__global__ __launch_bounds__(1024) void quantile_final_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
+                                                             float* __restrict__ thr, int64_t sb, const uint32_t* __restrict__ work)
+{
+    const int b = blockIdx.x;
+    const uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+    const int64_t n = (int64_t)HW * C;
+    const uint32_t cnt = w[PC_QW_BINS + 1];
+    if (cnt <= PC_QW_CAP) quantile_block<32, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, w[PC_QW_BINS + 4], w[PC_QW_BINS], q, thr + b);
+    else quantile_block<0, false>(scale + (int64_t)b * sb, ld, C, nullptr, n, n, 0u, 0u, q, thr + b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -453,17 +578,29 @@ int pc_eb_likelihood_launch(const int32_t* sym, int B, int HW, int C, const floa
     return PC_LAUNCH_CHECK();
 }
 
-int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t*, hipStream_t stream, int64_t sb)
+int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work, hipStream_t stream, int64_t sb)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
     if (sb == 0) sb = (int64_t)HW * ld;
     const int64_t n = (int64_t)HW * C;
+    static const bool single = [] { const char* v = std::getenv("PC_QUANTILE_SINGLE"); return v && std::atoi(v) != 0; }();
     if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else if (n <= 1024 * 32) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
-    else hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
+    else if (single) hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
+    else {
+        uint32_t* w = work;
+        if (!w && hipMallocAsync(reinterpret_cast<void**>(&w), pc_quantile_work_bytes(B), stream) != hipSuccess) return PC_ERR_HIP;
+        const int G = (int)std::min<int64_t>(64, (n + 16383) / 16384);
+        hipLaunchKernelGGL(quantile_zero_kernel, dim3(B), dim3(256), 0, stream, w);
+        hipLaunchKernelGGL(quantile_hist_kernel, dim3(G, B), dim3(1024), 0, stream, scale, ld, HW, C, sb, w);
+        hipLaunchKernelGGL(quantile_pick_kernel, dim3(B), dim3(256), 0, stream, n, q, w);
+        hipLaunchKernelGGL(quantile_collect_kernel, dim3(G, B), dim3(1024), 0, stream, scale, ld, HW, C, sb, w);
+        hipLaunchKernelGGL(quantile_final_kernel, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb, (const uint32_t*)w);
+        if (!work && hipFreeAsync(w, stream) != hipSuccess) return PC_ERR_HIP;
+    }
     return PC_LAUNCH_CHECK();
 }
-size_t pc_quantile_work_bytes(int) { return 0; }
+size_t pc_quantile_work_bytes(int B) { return (size_t)B * PC_QW_STRIDE * sizeof(uint32_t); }
 
 int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream)
 {
