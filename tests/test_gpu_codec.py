@@ -388,3 +388,27 @@ def test_cust_map_bit_exact_vs_oracle_and_reference_goldens(idx):
     if 0 < c["quality"] < 10 and c["mask_pol"] == "point-based-std":
         plain = net.compress(x.cuda(), c["quality"], c["mask_pol"])
         assert any(not torch.equal(a, b) for a, b in zip(plain["masks"], out["masks"]))
+
+
+def test_error_behaviour_of_the_wider_entry_points():
+    from progressivecodec_amd._lib import PcodecError
+    net = gpu_codec()
+    x = torch.rand(1, 3, 64, 64).cuda()
+    with pytest.raises(ValueError):
+        net.compress_levels(x, [], "point-based-std")
+    with pytest.raises(ValueError):
+        net.compress_levels(torch.rand(1, 3, 100, 64).cuda(), [0.5])
+    with pytest.raises(NotImplementedError):
+        net.forward_single_quality(x, 0.5, training=True)
+    with pytest.raises(NotImplementedError):
+        net.compress(x, 0.5, mask_pol="three-levels-learnable")
+    with pytest.raises(ValueError):
+        net.compress(x, 0.5, cust_map=torch.rand(1, 320, 8, 8))          # wrong map shape
+    d = net.compress_levels(x, [0, 0.5])
+    with pytest.raises(ValueError):
+        net.decompress_levels([d[0]["strings"]], d[0]["shape"], [0, 0.5])   # one entry per level
+    with pytest.raises(ValueError):
+        net.decompress_levels([d[0]["strings"], d[0]["strings"]], d[0]["shape"], [0, 0.5])   # level 0.5 without enhancement strings
+    bad = [[s[0][:6]] for s in d[1]["strings"][0]]
+    with pytest.raises(PcodecError):
+        net.decompress_levels([d[0]["strings"], [bad, d[1]["strings"][1]]], d[0]["shape"], [0, 0.5])
