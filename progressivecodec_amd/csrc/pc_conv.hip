@@ -324,9 +324,10 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     constexpr int NI = AIN + BIN;
     static_assert(AIN >= 1 && BIN >= 1 && A_PIECES % NLT == 0 && B_PIECES % NLT == 0, "tile / loader mismatch");
     static_assert((S - 2) * NI < 64, "vmcnt range");
+#if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer descriptors): the host pass only needs the launch stub
     extern __shared__ float4 smem[];                      // S stages, then the run table (launch_dma sizes it)
 
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave index in an SGPR
     unsigned long long t_entry = 0;
     if (STAMPS) t_entry = __builtin_amdgcn_s_memtime();
     // XCD-aware tile order (1-D grid).  Workgroups are handed to the 8 XCDs round-robin in dispatch order and every XCD has its
@@ -363,7 +364,23 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         // slip their few instructions in as soon as they are ready.
         __builtin_amdgcn_s_setprio(3);
         const int lw = wave - NMW;
-        int a_q[AIN]; int64_t a_pix[AIN]; uint32_t a_mask[AIN];
+        // Addressing: buffer (V#) form of the LDS-DMA load.  Per run the loaders hold two wave-uniform buffer descriptors
+        // (activations: base = segment pointer + tap offset + the tile's first pixel; weights: base = the run's weight block + the
+        // tile's first row), every lane keeps a 32-bit byte offset that is constant for the whole run, and the position inside the
+        // run is ONE scalar offset advanced per chunk.  A lane whose piece does not exist (tap outside the image, row beyond M or
+        // Cout, channel beyond the segment) carries an out-of-range offset: the hardware then writes zeros into LDS (checked on
+        // MI355X), which replaces the zero page and the per-DMA 64-bit select / pointer-increment VALU work of the `global_load_lds`
+        // form -- the loader waves were the long pole of every chunk (stamps: issue 1500-2700 cycles vs 1300-2000 of MFMA work).
+        constexpr int OOB = (int)0x80000000;               // >= num_records (0x7fffffff): reads as zero
+        int a_q[AIN], a_rel[AIN]; uint32_t a_mask[AIN];
+        // the tile's first pixel (row m0 of the GEMM); rows of a tile have increasing pixel indices, so offsets relative to it are
+        // small and non-negative whatever the tensor size (a 32-bit offset from the tensor start would overflow on Config 4)
+        int64_t pix0;
+        {
+            const int b = m0 / HoWo, r = m0 - b * HoWo;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            pix0 = ((int64_t)b * p.H + (int64_t)oy * p.stride) * p.W + (int64_t)ox * p.stride;
+        }
 #pragma unroll
         for (int i = 0; i < AIN; ++i) {
             const int pa = (lw * AIN + i) * 64 + lane;
@@ -371,33 +388,31 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
             a_q[i] = slot ^ pc_swz<KQ>(row);
             const int m = m0 + row;
             const bool ok = m < p.M;
-            const int mm = ok ? m : 0;
+            const int mm = ok ? m : m0;
             const int b = mm / HoWo, r = mm - b * HoWo;
             const int oy = r / p.Wo, ox = r - oy * p.Wo;
             const int iy0 = oy * p.stride, ix0 = ox * p.stride;
-            a_pix[i] = ((int64_t)b * p.H + iy0) * p.W + ix0;
+            a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
             uint32_t mask = 0;
             for (int t = 0; t < T; ++t) {
                 const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
                 if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
             }
-            a_mask[i] = (p.dbg & 4) ? 0u : mask;          // ablation 4: every DMA reads the zero page (no L2 traffic, same instruction stream)
+            a_mask[i] = (p.dbg & 4) ? 0u : mask;          // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
         }
-        int b_q[BIN]; int64_t b_row[BIN]; bool b_ok[BIN];
+        int b_q[BIN], b_off[BIN];
 #pragma unroll
         for (int i = 0; i < BIN; ++i) {
             const int pb = (lw * BIN + i) * 64 + lane;
             const int row = pb / KQ, slot = pb % KQ;
             b_q[i] = slot ^ pc_swz<KQ>(row);
-            b_ok[i] = n0 + row < p.Cout && !(p.dbg & 4);
-            b_row[i] = (int64_t)(n0 + row) * p.Cin;
+            b_off[i] = (n0 + row < p.Cout && !(p.dbg & 4)) ? (row * p.Cin + 4 * b_q[i]) * 4 : OOB;
         }
         // The K loop walks "runs" = (tap, segment) pairs.  In-kernel stamps (PC_CONV_DBG=64, profiles/r01_tune_tune14.log)
         // showed the loaders spending 1700-4700 cycles per chunk ISSUING 4-8 DMAs -- dependent scalar loads of the
         // tap / segment tables from the kernel-argument segment plus 64-bit address arithmetic -- while the MFMA waves
-        // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS, every
-        // loader thread keeps running source pointers that just advance by BK per chunk, and only a run boundary
-        // (every nch/BK chunks) touches the descriptor table.
+        // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS and only a run
+        // boundary (every nch/BK chunks) touches the descriptor table.
         pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
         const int nruns = T * p.nseg;
         for (int r = threadIdx.x - NLT; r < nruns; r += NLT) {
@@ -412,46 +427,57 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         }
         __syncthreads();                                   // run table visible (MFMA waves execute the matching barrier)
         const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
-        const float* a_ptr[AIN]; bool a_ok[AIN];
-        const float* b_ptr[BIN];
-        int run = 0, c_left = 0;
+        uint32_t ra_lo = 0, ra_hi = 0, rb_lo = 0, rb_hi = 0;      // the two descriptors' base addresses (wave-uniform)
+        int a_off[AIN];
+        int run = 0, c_left = 0, koff = 0;
         auto enter_run = [&](int r) {
             // The descriptor is read with hand-written ds_read_b128: behind a plain LDS load hipcc places `s_waitcnt vmcnt(0)`
             // (it must assume the read aliases an in-flight LDS-DMA), which would drain the prefetch pipeline at every run
-            // boundary.  The table is written once, before the first DMA, and no DMA targets it.
+            // boundary.  The table is written once, before the first DMA, and no DMA targets it.  readfirstlane: the values are
+            // wave-uniform, but an asm result lives in VGPRs and would make every later branch / descriptor look divergent.
             u32x4 lo, hi;
             asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                          : "=&v"(lo), "=&v"(hi) : "v"(runs_lds + (uint32_t)r * 32u) : "memory");
-            const float* d_a = reinterpret_cast<const float*>(((uint64_t)lo.y << 32) | lo.x);
-            const float* d_w = reinterpret_cast<const float*>(((uint64_t)lo.w << 32) | lo.z);
-            const int d_ld = (int)hi.x, d_nch = (int)hi.y, d_tap = (int)hi.z;
-            c_left = d_nch;
+            const uint64_t pa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.x);
+            const uint64_t pw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.z);
+            const int d_ld = __builtin_amdgcn_readfirstlane((int)hi.x), d_nch = __builtin_amdgcn_readfirstlane((int)hi.y);
+            const int d_tap = __builtin_amdgcn_readfirstlane((int)hi.z);
+            const float* d_a = reinterpret_cast<const float*>(pa) + pix0 * d_ld;
+            const float* d_w = reinterpret_cast<const float*>(pw) + (int64_t)n0 * p.Cin;
+            ra_lo = (uint32_t)(uintptr_t)d_a; ra_hi = (uint32_t)((uintptr_t)d_a >> 32);
+            rb_lo = (uint32_t)(uintptr_t)d_w; rb_hi = (uint32_t)((uintptr_t)d_w >> 32);
+            c_left = d_nch; koff = 0;
 #pragma unroll
-            for (int i = 0; i < AIN; ++i) {
-                a_ptr[i] = d_a + a_pix[i] * d_ld + 4 * a_q[i];
-                a_ok[i] = (a_mask[i] >> d_tap) & 1u;
-            }
-#pragma unroll
-            for (int i = 0; i < BIN; ++i) b_ptr[i] = d_w + b_row[i] + 4 * b_q[i];
+            for (int i = 0; i < AIN; ++i) a_off[i] = ((a_mask[i] >> d_tap) & 1u) ? (a_rel[i] * d_ld + 4 * a_q[i]) * 4 : OOB;
         };
         enter_run(0);
         auto issue = [&](int stage) {
             float4* lds_a = smem + stage * STAGE + lw * AIN * 64;
             float4* lds_b = smem + stage * STAGE + A_PIECES + lw * BIN * 64;
+            // descriptors rebuilt from readfirstlane'd halves: hipcc must SEE they are scalar, or it wraps every load in a waterfall loop
+            auto mk = [](uint32_t lo, uint32_t hi) {
+                const uint64_t a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+                return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a), 0, 0x7fffffff, 0x00020000);
+            };
+            const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
+            if (c_left >= BK) {
 #pragma unroll
-            for (int i = 0; i < AIN; ++i) {
-                const float* src = (a_ok[i] && 4 * a_q[i] < c_left) ? a_ptr[i] : pc_zero_page;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16, 0, 0);
-                a_ptr[i] += BK;
-            }
+                for (int i = 0; i < AIN; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16, a_off[i], koff, 0, 0);
 #pragma unroll
-            for (int i = 0; i < BIN; ++i) {
-                const float* src = (b_ok[i] && 4 * b_q[i] < c_left) ? b_ptr[i] : pc_zero_page;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                                 (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16, 0, 0);
-                b_ptr[i] += BK;
+                for (int i = 0; i < BIN; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16, b_off[i], koff, 0, 0);
+            } else {                                        // last, partial chunk of a segment whose channel count is not a multiple of BK
+#pragma unroll
+                for (int i = 0; i < AIN; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16,
+                                                             4 * a_q[i] < c_left ? a_off[i] : OOB, koff, 0, 0);
+#pragma unroll
+                for (int i = 0; i < BIN; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16,
+                                                             4 * b_q[i] < c_left ? b_off[i] : OOB, koff, 0, 0);
             }
+            koff += BK * 4;
             c_left -= BK;
             if (c_left <= 0 && ++run < nruns) enter_run(run);
         };
@@ -565,6 +591,7 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         pc_dbg_stamps[blk][8] = t_loop - t_entry; pc_dbg_stamps[blk][9] = __builtin_amdgcn_s_memtime() - t_epi;
         pc_dbg_stamps[blk][10] = t_epi - t_loop; pc_dbg_stamps[blk][11] = r_epi - r_loop;   // in-kernel clock = [10]/[11] x 100 MHz
     }
+#endif
 }
 
 template <int BK, int S, int WM, int WN, bool SQ = false>
