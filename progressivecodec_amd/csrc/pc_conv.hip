@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // ------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(64))) float pc_zero_page[16];
 // diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop phases, [block][8]
-__device__ unsigned long long pc_dbg_stamps[8192][12];
+__device__ unsigned long long pc_dbg_stamps[8192][16];
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -393,12 +393,14 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
             const int oy = r / p.Wo, ox = r - oy * p.Wo;
             const int iy0 = oy * p.stride, ix0 = ox * p.stride;
             a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
+            // (every instruction of this prologue costs ~40 cycles while other workgroups' MFMA waves saturate the SIMD -- stamps:
+            // 10 k cycles for 9 taps, 45 k for 25; holding all taps in SGPRs up front changed nothing, profiles/r01_tune_tune31.log)
             uint32_t mask = 0;
             for (int t = 0; t < T; ++t) {
                 const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
-                if (ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
             }
-            a_mask[i] = (p.dbg & 4) ? 0u : mask;          // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
+            a_mask[i] = (ok && !(p.dbg & 4)) ? mask : 0u;   // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
         }
         int b_q[BIN], b_off[BIN];
 #pragma unroll
@@ -413,6 +415,8 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         // tap / segment tables from the kernel-argument segment plus 64-bit address arithmetic -- while the MFMA waves
         // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS and only a run
         // boundary (every nch/BK chunks) touches the descriptor table.
+        unsigned long long t_masks = 0, t_table = 0;
+        if (STAMPS) t_masks = __builtin_amdgcn_s_memtime();
         pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
         const int nruns = T * p.nseg;
         for (int r = threadIdx.x - NLT; r < nruns; r += NLT) {
@@ -426,6 +430,7 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
             runs[r] = d;
         }
         __syncthreads();                                   // run table visible (MFMA waves execute the matching barrier)
+        if (STAMPS) t_table = __builtin_amdgcn_s_memtime();
         const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
         uint32_t ra_lo = 0, ra_hi = 0, rb_lo = 0, rb_hi = 0;      // the two descriptors' base addresses (wave-uniform)
         int a_off[AIN];
@@ -486,6 +491,10 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         for (; issued < S - 1 && issued < nchunks; ++issued) { issue(st_issue); st_issue = st_issue + 1 == S ? 0 : st_issue + 1; }
         pc_wait_chunks<NI, S - 2>(issued - 1);             // chunk 0 landed
         __builtin_amdgcn_s_barrier();
+        if (STAMPS && wave == NMW && lane == 0 && blk < 8192) {
+            pc_dbg_stamps[blk][12] = t_masks - t_entry; pc_dbg_stamps[blk][13] = t_table - t_masks;
+            pc_dbg_stamps[blk][14] = __builtin_amdgcn_s_memtime() - t_table;
+        }
         unsigned long long s_issue = 0, s_dma = 0, s_bar = 0;
         for (int c = 0; c < nchunks; ++c) {
             unsigned long long t0 = 0, t1 = 0, t2 = 0;
@@ -634,7 +643,7 @@ hipError_t launch_cfg(const pc_conv_params& p, hipStream_t stream)
 extern "C" __attribute__((visibility("default"))) int pc_debug_read_stamps(unsigned long long* dst, int nblocks)
 {
     if (!dst || nblocks <= 0 || nblocks > 8192) return PC_ERR_ARG;
-    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pc_dbg_stamps), sizeof(unsigned long long) * 12 * (size_t)nblocks) == hipSuccess ? PC_OK : PC_ERR_HIP;
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(pc_dbg_stamps), sizeof(unsigned long long) * 16 * (size_t)nblocks) == hipSuccess ? PC_OK : PC_ERR_HIP;
 }
 
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)

@@ -70,13 +70,14 @@ def main():
             print(f"{name:10s} M={B*Ho*Wo:7d} N={co:4d} K={k*k*ci:5d} cfg {cfg}: {us:9.1f} us  {flops/us/1e6:6.1f} TFLOP/s", flush=True)
             if int(os.environ.get("PC_CONV_DBG", "0")) & 64:
                 nb = min(8192, ((B * Ho * Wo + 63) // 64) * ((co + 63) // 64))
-                st = np.zeros((nb, 12), np.uint64)
+                st = np.zeros((nb, 16), np.uint64)
                 check(L.pc_debug_read_stamps(st.ctypes.data_as(C.c_void_p), nb))
                 st = st.astype(np.float64)
                 n = st[:, 3].mean()
                 print(f"   per chunk (cycles, mean over {nb} blocks, {n:.0f} chunks): loader issue {st[:,0].mean()/n:7.0f}  dma wait {st[:,1].mean()/n:7.0f}  "
                       f"loader barrier wait {st[:,2].mean()/n:7.0f} | mfma wave0 compute {st[:,4].mean()/n:7.0f} barrier wait {st[:,5].mean()/n:7.0f} | "
                       f"wave1 compute {st[:,6].mean()/n:7.0f} barrier wait {st[:,7].mean()/n:7.0f}", flush=True)
+                print(f"   loader prologue (cycles): rows/masks/offsets {st[:,12].mean():7.0f}  run table + barrier {st[:,13].mean():7.0f}  first chunk issued + landed {st[:,14].mean():7.0f}")
                 print(f"   per block (cycles): prologue {st[:,8].mean():7.0f}  K loop {(st[:,4]+st[:,5]).mean():8.0f}  epilogue {st[:,9].mean():7.0f}  "
                       f"| in-kernel clock over the K loop (s_memtime / s_memrealtime x 100 MHz, median over blocks) "
                       f"{np.median(st[:,10] / np.maximum(st[:,11], 1)) * 0.1:5.2f} GHz", flush=True)
