@@ -30,6 +30,9 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <vector>
 
 #include "../../include/pc_math.h"
 #include "pc_device.h"
@@ -376,31 +379,47 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
         // the tile's first pixel (row m0 of the GEMM); rows of a tile have increasing pixel indices, so offsets relative to it are
         // small and non-negative whatever the tensor size (a 32-bit offset from the tensor start would overflow on Config 4)
         int64_t pix0;
-        {
-            const int b = m0 / HoWo, r = m0 - b * HoWo;
-            const int oy = r / p.Wo, ox = r - oy * p.Wo;
-            pix0 = ((int64_t)b * p.H + (int64_t)oy * p.stride) * p.W + (int64_t)ox * p.stride;
-        }
+        if (p.rowtab) {
+            // rows -> (input pixel, tap mask) from the table cached per layer geometry (pc_conv_launch): two loads per row instead of
+            // two integer divisions and a loop over the taps.  Any instruction of this prologue costs ~40 cycles while other
+            // workgroups' MFMA waves saturate the SIMD, and the first workgroups' prologue is exposed on every one of the 543
+            // dependent launches of a step (stamps: 10 k cycles at 9 taps, 45 k at 25 before).
+            pix0 = p.rowtab[m0];
 #pragma unroll
-        for (int i = 0; i < AIN; ++i) {
-            const int pa = (lw * AIN + i) * 64 + lane;
-            const int row = pa / KQ, slot = pa % KQ;
-            a_q[i] = slot ^ pc_swz<KQ>(row);
-            const int m = m0 + row;
-            const bool ok = m < p.M;
-            const int mm = ok ? m : m0;
-            const int b = mm / HoWo, r = mm - b * HoWo;
-            const int oy = r / p.Wo, ox = r - oy * p.Wo;
-            const int iy0 = oy * p.stride, ix0 = ox * p.stride;
-            a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
-            // (every instruction of this prologue costs ~40 cycles while other workgroups' MFMA waves saturate the SIMD -- stamps:
-            // 10 k cycles for 9 taps, 45 k for 25; holding all taps in SGPRs up front changed nothing, profiles/r01_tune_tune31.log)
-            uint32_t mask = 0;
-            for (int t = 0; t < T; ++t) {
-                const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+            for (int i = 0; i < AIN; ++i) {
+                const int pa = (lw * AIN + i) * 64 + lane;
+                const int row = pa / KQ, slot = pa % KQ;
+                a_q[i] = slot ^ pc_swz<KQ>(row);
+                const int m = m0 + row;
+                const bool ok = m < p.M;
+                a_rel[i] = ok ? p.rowtab[m] - (int)pix0 : 0;
+                a_mask[i] = (ok && !(p.dbg & 4)) ? (uint32_t)p.rowtab[(size_t)(1 + phase) * p.M + m] : 0u;
             }
-            a_mask[i] = (ok && !(p.dbg & 4)) ? mask : 0u;   // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
+        } else {
+            {
+                const int b = m0 / HoWo, r = m0 - b * HoWo;
+                const int oy = r / p.Wo, ox = r - oy * p.Wo;
+                pix0 = ((int64_t)b * p.H + (int64_t)oy * p.stride) * p.W + (int64_t)ox * p.stride;
+            }
+#pragma unroll
+            for (int i = 0; i < AIN; ++i) {
+                const int pa = (lw * AIN + i) * 64 + lane;
+                const int row = pa / KQ, slot = pa % KQ;
+                a_q[i] = slot ^ pc_swz<KQ>(row);
+                const int m = m0 + row;
+                const bool ok = m < p.M;
+                const int mm = ok ? m : m0;
+                const int b = mm / HoWo, r = mm - b * HoWo;
+                const int oy = r / p.Wo, ox = r - oy * p.Wo;
+                const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+                a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
+                uint32_t mask = 0;
+                for (int t = 0; t < T; ++t) {
+                    const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+                }
+                a_mask[i] = (ok && !(p.dbg & 4)) ? mask : 0u;   // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
+            }
         }
         int b_q[BIN], b_off[BIN];
 #pragma unroll
@@ -603,6 +622,57 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
 #endif
 }
 
+// ---- per-geometry row tables of the LDS-DMA kernel (see its prologue) ----
+__global__ void conv_rowtab_kernel(const pc_conv_params p, int* __restrict__ tab)
+{
+    const int HoWo = p.Ho * p.Wo;
+    for (int m = blockIdx.x * blockDim.x + threadIdx.x; m < p.M; m += gridDim.x * blockDim.x) {
+        const int b = m / HoWo, r = m - b * HoWo;
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+        tab[m] = (b * p.H + iy0) * p.W + ix0;
+        for (int ph = 0; ph < p.nphase; ++ph) {
+            uint32_t mask = 0;
+            for (int t = 0; t < p.ntap[ph]; ++t) {
+                const int iy = iy0 + p.dy[ph][t], ix = ix0 + p.dx[ph][t];
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+            }
+            tab[(size_t)(1 + ph) * p.M + m] = (int)mask;
+        }
+    }
+}
+
+struct RowTabKey {
+    int dev, B, H, W, stride, nphase, Ho, Wo, M, ntap[4];
+    int dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
+    bool operator==(const RowTabKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
+};
+struct RowTabEntry { RowTabKey key; int* tab; };
+
+// returns the cached table for this layer geometry, building it on first use (synchronously: other streams may use it right away)
+const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
+{
+    static std::mutex mu;
+    static std::vector<RowTabEntry> cache;
+    if ((int64_t)p.B * p.H * p.W >= (int64_t)1 << 31) return nullptr;          // pixel indices are int32 in the table
+    RowTabKey k;
+    std::memset(&k, 0, sizeof(k));
+    (void)hipGetDevice(&k.dev);
+    k.B = p.B; k.H = p.H; k.W = p.W; k.stride = p.stride; k.nphase = p.nphase; k.Ho = p.Ho; k.Wo = p.Wo; k.M = p.M;
+    for (int ph = 0; ph < p.nphase; ++ph) {
+        k.ntap[ph] = p.ntap[ph];
+        for (int t = 0; t < p.ntap[ph]; ++t) { k.dy[ph][t] = p.dy[ph][t]; k.dx[ph][t] = p.dx[ph][t]; }
+    }
+    std::lock_guard<std::mutex> lk(mu);
+    for (const RowTabEntry& e : cache) if (e.key == k) return e.tab;
+    int* tab = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&tab), (size_t)(1 + p.nphase) * p.M * sizeof(int)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, tab);
+    if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(tab); return nullptr; }
+    cache.push_back(RowTabEntry{k, tab});
+    return tab;
+}
+
 template <int BK, int S, int WM, int WN, bool SQ = false>
 hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
 {
@@ -658,6 +728,12 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
     if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
     static const int dbg_env = [] { const char* v = std::getenv("PC_CONV_DBG"); return v ? std::atoi(v) : 0; }();
     if (dbg_env) const_cast<pc_conv_params&>(p).dbg = dbg_env;
+    {   // row tables only pay for layers with several taps (1x1 layers: one tap, always valid)
+        int tmax = 0;
+        for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
+        static const bool no_tab = [] { const char* v = std::getenv("PC_CONV_NO_ROWTAB"); return v && std::atoi(v) != 0; }();
+        const_cast<pc_conv_params&>(p).rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
+    }
     const_cast<pc_conv_params&>(p).dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&
                                                p.outW == p.Wo && !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx &&
                                                p.out_sb == (int64_t)p.outH * p.out_sy;
