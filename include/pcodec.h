@@ -189,6 +189,15 @@ PC_API int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strin
                                       const uint8_t* const* z_strings, const size_t* z_lens, int B, int zh, int zw,
                                       const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream);
 
+/* Bulk string transfer (binding overhead: 672 strings per Config-2 batch).  After a compress: _strings_size gives the total byte count
+ * and the number of strings (all y slots, images inside a slot, then the z strings); _copy_strings concatenates them into dst (cap bytes)
+ * and writes their lengths.  _decompress_packed takes the same layout: y strings of slots 0 .. 10+10*n_levels-1 (B each; empty strings
+ * for the slots of quality-0 levels), then B z strings. */
+PC_API int pc_codec_strings_size(const pc_codec* c, size_t* total_bytes, int* n_strings);
+PC_API int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens);
+PC_API int pc_codec_decompress_packed(pc_codec* c, const uint8_t* data, const size_t* lens, int B, int zh, int zw,
+                                      const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream);
+
 /* forward_single_quality in eval mode (models/CHProg_cnn.py:1002-1198) -- SURVEY.md section 8(f) rank 2: the rate-estimation path
  * behind test_epoch / valid_epoch (training/step.py:215-267).  Runs the encoder chain without entropy coding and returns the
  * likelihood tensors: y_lik device [B][320 or 640][H/16][W/16] (640 when quality != 0), z_lik device [B][192][H/64][W/64],

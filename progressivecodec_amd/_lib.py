@@ -19,7 +19,8 @@ EXPORTS = [
     "pc_codec_set_tensor", "pc_codec_set_tables", "pc_codec_finalize", "pc_codec_set_threads", "pc_codec_compress",
     "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
-    "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map",
+    "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
+    "pc_codec_decompress_packed",
 ]
 
 
@@ -78,6 +79,9 @@ def lib():
         L.pc_codec_get_level_string.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.pc_codec_decompress_levels.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.pc_codec_set_cust_map.argtypes = [vp, vp]
+        L.pc_codec_strings_size.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int)]
+        L.pc_codec_copy_strings.argtypes = [vp, vp, sz, vp]
+        L.pc_codec_decompress_packed.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.pc_codec_forward.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp, vp, vp, vp]
         L.pc_codec_read_tap.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
         L.pc_codec_read_tap_i32.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]

@@ -1297,6 +1297,31 @@ extern "C" int pc_codec_compress_levels(pc_codec* c, const float* x, int B, int 
     return compress_impl(c, x, B, H, W, qualities, n_levels, mask_pol, masks_out, (hipStream_t)stream);
 }
 
+// Bulk transfer of the last compress()'s strings: one copy instead of one call per string (672 strings at Config 2; the per-call
+// overhead of a ctypes / cgo / JNI binding is what this avoids).  Order: slot 0..res_slices-1, images 0..B-1 inside a slot, then z.
+extern "C" int pc_codec_strings_size(const pc_codec* c, size_t* total_bytes, int* n_strings)
+{
+    if (!c || !total_bytes || !n_strings) return PC_ERR_ARG;
+    size_t t = 0;
+    for (const auto& s : c->y_strings) t += s.size();
+    for (const auto& s : c->z_strings) t += s.size();
+    *total_bytes = t; *n_strings = (int)(c->y_strings.size() + c->z_strings.size());
+    return PC_OK;
+}
+
+extern "C" int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens)
+{
+    if (!c || !dst || !lens) return PC_ERR_ARG;
+    size_t off = 0, k = 0;
+    for (const std::vector<std::vector<uint8_t>>* v : {&c->y_strings, &c->z_strings})
+        for (const auto& s : *v) {
+            if (off + s.size() > cap) return PC_ERR_ARG;
+            if (!s.empty()) std::memcpy(dst + off, s.data(), s.size());
+            off += s.size(); lens[k++] = s.size();
+        }
+    return PC_OK;
+}
+
 extern "C" int pc_codec_get_level_string(const pc_codec* c, int level, int slice, int b, const uint8_t** data, size_t* len)
 {
     if (!c || !data || !len || b < 0 || b >= c->res_B || level < 0 || level >= (int)c->res_level_coded.size()) return PC_ERR_ARG;
@@ -1442,6 +1467,19 @@ extern "C" int pc_codec_decompress(pc_codec* c, const uint8_t* const* y_strings,
 {
     if (n_slices < (quality == 0 ? NS0 : 2 * NS0)) return PC_ERR_ARG;
     return decompress_impl(c, y_strings, y_lens, z_strings, z_lens, B, zh, zw, &quality, 1, mask_pol, x_hat, (hipStream_t)stream);
+}
+
+// decompress_levels from ONE buffer: data = the y strings in slot order ([(10 + 10*n_levels)][B], empty for quality-0 levels) followed
+// by the B z strings, lens = their lengths in that order (the layout pc_codec_copy_strings produces)
+extern "C" int pc_codec_decompress_packed(pc_codec* c, const uint8_t* data, const size_t* lens, int B, int zh, int zw,
+                                          const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream)
+{
+    if (!c || !data || !lens || B <= 0 || n_levels < 1) return PC_ERR_ARG;
+    const size_t ny = (size_t)(NS0 + NS0 * n_levels) * B;
+    std::vector<const uint8_t*> ptr(ny + B);
+    size_t off = 0;
+    for (size_t i = 0; i < ny + B; ++i) { ptr[i] = data + off; off += lens[i]; }
+    return decompress_impl(c, ptr.data(), lens, ptr.data() + ny, lens + ny, B, zh, zw, qualities, n_levels, mask_pol, x_hat, (hipStream_t)stream);
 }
 
 extern "C" int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strings, const size_t* y_lens,

@@ -123,6 +123,33 @@ class ChannelProgresssiveWACNN:
         import torch
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
+    def _fetch_strings(self):
+        """every byte string of the last compress as a flat list (slot-major, then z), through one bulk copy"""
+        tot, n = C.c_size_t(), C.c_int()
+        check(lib().pc_codec_strings_size(self._h, C.byref(tot), C.byref(n)), "pc_codec_strings_size")
+        buf = C.create_string_buffer(max(1, tot.value))
+        lens = (C.c_size_t * n.value)()
+        check(lib().pc_codec_copy_strings(self._h, buf, tot.value, lens), "pc_codec_copy_strings")
+        raw = buf.raw
+        out, off = [], 0
+        for k in lens:
+            out.append(raw[off:off + k])
+            off += k
+        return out
+
+    def _decompress_packed(self, slots, z_strings, B, zh, zw, qualities, mask_pol):
+        """slots: list of B-lists of byte strings in slot order; returns x_hat [L, B, 3, H, W]"""
+        import torch
+        flat = [s for sl in slots for s in sl] + list(z_strings)
+        data = b"".join(flat)
+        lens = (C.c_size_t * len(flat))(*map(len, flat))
+        L = len(qualities)
+        qa = (C.c_double * L)(*qualities)
+        x_hat = torch.empty((L, B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
+        check(lib().pc_codec_decompress_packed(self._h, data, lens, B, zh, zw, qa, L, _MASK_POL[mask_pol], C.c_void_p(x_hat.data_ptr()),
+                                               self._stream()), "pc_codec_decompress_packed")
+        return x_hat
+
     def _set_cust_map(self, cust_map, B, h, w):
         """cust_map: [B, 320, H/16, W/16] importance map whose per-slice quantile replaces the scale's (layers/masking.py:171-194).
         Returns the device tensor (keep it alive until the call has been issued)."""
@@ -158,14 +185,9 @@ class ChannelProgresssiveWACNN:
                                       C.c_void_p(masks.data_ptr()) if masks is not None else None, self._stream()),
               "pc_codec_compress")
         ns = lib().pc_codec_num_slices(self._h)
-        p, n = C.c_void_p(), C.c_size_t()
-
-        def get(s, b):
-            check(lib().pc_codec_get_string(self._h, s, b, C.byref(p), C.byref(n)), "pc_codec_get_string")
-            return C.string_at(p, n.value)
-
-        y_strings = [[get(s, b) for b in range(B)] for s in range(ns)]
-        z_strings = [get(-1, b) for b in range(B)]
+        strs = self._fetch_strings()                                             # all slots, then z: one copy
+        y_strings = [strs[s * B:(s + 1) * B] for s in range(ns)]
+        z_strings = strs[-B:]
         return {"strings": [y_strings, z_strings], "shape": torch.Size([H // 64, W // 64]),
                 "masks": [masks[i] for i in range(10)] if masks is not None else []}
 
@@ -185,17 +207,12 @@ class ChannelProgresssiveWACNN:
         if any(len(s) != B for s in y_strings):
             raise ValueError("Invalid strings or indexes parameters")            # entropy_models.py:253-254
         zh, zw = int(shape[0]), int(shape[1])
-        flat = [s for sl in y_strings for s in sl]
-        keep = flat + list(z_strings)                                            # keep the bytes objects alive
-        yp = (C.c_char_p * len(flat))(*flat)
-        yl = (C.c_size_t * len(flat))(*[len(s) for s in flat])
-        zp = (C.c_char_p * B)(*z_strings)
-        zl = (C.c_size_t * B)(*[len(s) for s in z_strings])
-        x_hat = torch.empty((B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
+        if ns < (10 if quality == 0 else 20):
+            raise ValueError("Invalid strings or indexes parameters")
         cm = self._set_cust_map(cust_map if quality > 0 else None, B, 4 * zh, 4 * zw)                     # CHProg_cnn.py:850-851
-        check(lib().pc_codec_decompress(self._h, yp, yl, ns, zp, zl, B, zh, zw, float(quality), _MASK_POL[mask_pol],
-                                        C.c_void_p(x_hat.data_ptr()), self._stream()), "pc_codec_decompress")
-        del keep
+        slots = [list(sl) for sl in y_strings[:20]] + [[b""] * B for _ in range(20 - min(ns, 20))]
+        x_hat = self._decompress_packed(slots, z_strings, B, zh, zw, [float(quality)], mask_pol)[0]
+        del cm
         return {"x_hat": x_hat}
 
     # ------------------------------------------------------------------ likelihood (rate estimation) path
@@ -256,17 +273,13 @@ class ChannelProgresssiveWACNN:
         qa = (C.c_double * L)(*qualities)
         check(lib().pc_codec_compress_levels(self._h, C.c_void_p(x.data_ptr()), B, H, W, qa, L, _MASK_POL[mask_pol], mp, self._stream()),
               "pc_codec_compress_levels")
-        p, n = C.c_void_p(), C.c_size_t()
-
-        def get(lv, s, b):
-            check(lib().pc_codec_get_level_string(self._h, lv, s, b, C.byref(p), C.byref(n)), "pc_codec_get_level_string")
-            return C.string_at(p, n.value)
-
-        z_strings = [get(0, -1, b) for b in range(B)]
-        base = [[get(0, s, b) for b in range(B)] for s in range(10)]
+        strs = self._fetch_strings()                                             # slots [10 + 10*L][B], then z
+        slot = lambda k: strs[k * B:(k + 1) * B]
+        z_strings = strs[-B:]
+        base = [slot(s) for s in range(10)]
         out = []
         for lv, q in enumerate(qualities):
-            enh = [[get(lv, s, b) for b in range(B)] for s in range(10, 20)] if q > 0 else []
+            enh = [slot(10 + 10 * lv + s) for s in range(10)] if q > 0 else []
             out.append({"strings": [base + enh, z_strings], "shape": torch.Size([H // 64, W // 64]),
                         "masks": [masks[lv][i] for i in range(10)] if masks[lv] is not None else []})
         return out
@@ -305,16 +318,7 @@ class ChannelProgresssiveWACNN:
                 slots += [[b""] * B for _ in range(10)]
         if any(len(sl) != B for sl in slots):
             raise ValueError("Invalid strings or indexes parameters")
-        flat = [s for sl in slots for s in sl]
-        yp = (C.c_char_p * len(flat))(*flat)
-        yl = (C.c_size_t * len(flat))(*[len(s) for s in flat])
-        zp = (C.c_char_p * B)(*z_strings)
-        zl = (C.c_size_t * B)(*[len(s) for s in z_strings])
-        qa = (C.c_double * L)(*qualities)
-        x_hat = torch.empty((L, B, 3, 64 * zh, 64 * zw), device=self.device, dtype=torch.float32)
-        check(lib().pc_codec_decompress_levels(self._h, yp, yl, zp, zl, B, zh, zw, qa, L, _MASK_POL[mask_pol],
-                                               C.c_void_p(x_hat.data_ptr()), self._stream()), "pc_codec_decompress_levels")
-        del flat
+        x_hat = self._decompress_packed(slots, z_strings, B, zh, zw, qualities, mask_pol)
         return [{"x_hat": x_hat[lv]} for lv in range(L)]
 
     # ------------------------------------------------------------------ test taps
