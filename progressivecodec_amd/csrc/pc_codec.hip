@@ -87,6 +87,8 @@ struct pc_codec {
     int res_slices = 0, res_B = 0;               // res_slices = string slots: 10 base + 10 per coded level
     std::vector<char> res_level_coded;            // per level of the last compress: enhancement strings present (quality > 0)
     std::vector<hipEvent_t> lvl_events;           // D2H completion of the base pass / of each level
+    hipStream_t copy_stream = nullptr;            // per-slice D2H of the last pass (streamed entropy coding)
+    std::vector<hipEvent_t> slice_ev;             // [2*NS0]: prep done / copied, per slice of that pass
     std::vector<std::vector<uint8_t>> y_strings;  // [slot*B + b]; slot = slice (base) or 10 + 10*level + (slice - 10)
     std::vector<std::vector<uint8_t>> z_strings;  // [b]
     int n_threads = 0;
@@ -921,6 +923,8 @@ struct ChainCtx {
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
     const float* cust_map;                      // NCHW [B][320][HW]: enhancement masks threshold this map instead of the scale
+    int32_t *so_sym, *so_idx;                   // streamed pass (single lane): pinned destinations; slice i of the pass is copied to
+                                                // so_sym + i*M*SLICE on c->copy_stream as soon as its prep kernel is done
 };
 
 template <typename T> inline T* img(T* p, int b0, size_t per_image) { return p ? p + (size_t)b0 * per_image : nullptr; }
@@ -1043,6 +1047,15 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
                               c->scale_table, c->n_table, c->scale_bound, k.sym + so, k.idx + so, m,
                               img(k.ye, b0, pi * D0) + 32 * i, D0, lik, lik_sb, sA,
                               k.cust_map ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi));
+        }
+        if (k.so_sym && b0 == 0 && nb == k.B) {                                          // hand this slice's symbols to the host now
+            const int i = step - k.step0;
+            const size_t ns = k.M * SLICE;
+            HIPCHK(hipEventRecord(c->slice_ev[i], sA));
+            HIPCHK(hipStreamWaitEvent(c->copy_stream, c->slice_ev[i], 0));
+            HIPCHK(hipMemcpyAsync(k.so_sym + (size_t)i * ns, k.sym + so, ns * 4, hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(hipMemcpyAsync(k.so_idx + (size_t)i * ns, k.idx + so, ns * 4, hipMemcpyDeviceToHost, c->copy_stream));
+            HIPCHK(hipEventRecord(c->slice_ev[NS0 + i], c->copy_stream));
         }
         PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
     }
@@ -1254,14 +1267,46 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         t_enc_last = now() - te;                             // pure host rANS time of this pass (the last one is not overlapped)
         return r;
     };
+    // The LAST coded level has no later GPU pass to hide its entropy coding behind: with a single encoder lane its slices are copied
+    // out one by one (side stream) and coded while the rest of the chain still runs; only the last slice's coding is exposed.
+    int last_coded = -1;
+    for (int l = 0; l < n_levels; ++l) if (!(qualities[l] <= 0)) last_coded = l;
+    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return v && std::atoi(v) != 0; }();
+    const bool can_stream = !no_stream && lane_count(c, B, false) == 1;
+    if (can_stream && !c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        c->slice_ev.resize(2 * NS0);
+        for (auto& e : c->slice_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
     for (int l = 0; l < n_levels; ++l) {
         if (qualities[l] <= 0) continue;                                                 // base only: nothing level-specific to code
         k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
         k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);   // a custom map overrides the policy
         k.masks = masks_out ? masks_out[l] : nullptr;
-        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :775-845
         const int bufsel = n_coded & 1;
         const size_t off = (size_t)(1 + bufsel) * n_half;
+        if (can_stream && l == last_coded) {
+            k.so_sym = c->h_sym + off; k.so_idx = c->h_idx + off;
+            PCCHK(run_chain(k, st, false, nullptr, nullptr));                            // :775-845, slices streamed out
+            k.so_sym = k.so_idx = nullptr;
+            c->res_level_coded[l] = 1;
+            ++n_coded;
+            int r = drain(pending, pending_buf);                                         // the pass before, meanwhile
+            if (r != PC_OK) rc = r;
+            pending = -2;                                                                // nothing left to drain afterwards
+            const double te = now();
+            for (int i = 0; i < NS0; ++i) {
+                HIPCHK(hipEventSynchronize(c->slice_ev[NS0 + i]));
+                const double ts = now();
+                r = encode_streams(c, c->h_sym + off + (size_t)i * M * SLICE, c->h_idx + off + (size_t)i * M * SLICE, NS0 + NS0 * l + i, 1, B, per,
+                                   nullptr, nullptr, per_z);
+                if (r != PC_OK) rc = r;
+                if (i == NS0 - 1) t_enc_last = now() - ts;
+            }
+            t_host += now() - te;
+            continue;
+        }
+        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :775-845
         HIPCHK(hipMemcpyAsync(c->h_sym + off, k.sym + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(c->h_idx + off, k.idx + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(c->lvl_events[1 + l], st));
@@ -1272,8 +1317,10 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         if (r != PC_OK) rc = r;
         pending = l; pending_buf = bufsel;
     }
-    const int r = drain(pending, pending_buf);
-    if (r != PC_OK) rc = r;
+    if (pending != -2) {
+        const int r = drain(pending, pending_buf);
+        if (r != PC_OK) rc = r;
+    }
     HIPCHK(hipStreamSynchronize(st));                                                    // masks_out complete for the caller
     if (timing) std::fprintf(stderr, "[pcodec] compress: %d level(s), %d coded; total %.2f ms; host rANS of the last pass (exposed) %.2f ms\n",
                              n_levels, n_coded, now() - t0, t_enc_last);
