@@ -88,6 +88,8 @@ struct pc_codec {
     std::vector<char> res_level_coded;            // per level of the last compress: enhancement strings present (quality > 0)
     std::vector<hipEvent_t> lvl_events;           // D2H completion of the base pass / of each level
     hipStream_t copy_stream = nullptr;            // per-slice D2H of the last pass (streamed entropy coding)
+    hipStream_t pipe_stream = nullptr;            // enhancement chain when it is pipelined against the base chain
+    std::vector<hipEvent_t> pipe_ev;              // [NS0] base slice i complete, [NS0] pipeline fork, [NS0+1] pipeline join
     std::vector<hipEvent_t> slice_ev;             // [2*NS0]: prep done / copied, per slice of that pass
     std::vector<std::vector<uint8_t>> y_strings;  // [slot*B + b]; slot = slice (base) or 10 + 10*level + (slice - 10)
     std::vector<std::vector<uint8_t>> z_strings;  // [b]
@@ -923,6 +925,11 @@ struct ChainCtx {
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
     const float* cust_map;                      // NCHW [B][320][HW]: enhancement masks threshold this map instead of the scale
+    hipEvent_t* sig;                            // if set: record sig[i] on the lane's stream once slice i (of this pass) is complete
+    std::atomic<int>* sig_count;                //         ... and publish the number of recorded events to other host threads
+    hipEvent_t* waitv;                          // if set: slice i of this pass starts only after waitv[i] (recorded by the other chain)
+    std::atomic<int>* wait_count;               //         host side: do not look at waitv[i] before it has been recorded
+    size_t h_off;                               // decoder: offset (int32 units) of this chain's region in the pinned staging buffers
     int32_t *so_sym, *so_idx;                   // streamed pass (single lane): pinned destinations; slice i of the pass is copied to
                                                 // so_sym + i*M*SLICE on c->copy_stream as soon as its prep kernel is done
 };
@@ -1030,6 +1037,11 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     pc_codec* c = k.c;
     const size_t pi = (size_t)k.HW;
     for (int step = k.step0; step < k.step1; ++step) {
+        if (k.waitv) {                                                                   // pipelined against the other chain
+            const int i = step >= NS0 ? step - NS0 : step;
+            if (k.wait_count) while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+            HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
+        }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         // forward path: likelihood of slice `step` of image b at lik[((b * lik_nch) + 32 * step + c) * HW + p]
@@ -1049,7 +1061,7 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
                               k.cust_map ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi));
         }
         if (k.so_sym && b0 == 0 && nb == k.B) {                                          // hand this slice's symbols to the host now
-            const int i = step - k.step0;
+            const int i = step >= NS0 ? step - NS0 : step;
             const size_t ns = k.M * SLICE;
             HIPCHK(hipEventRecord(c->slice_ev[i], sA));
             HIPCHK(hipStreamWaitEvent(c->copy_stream, c->slice_ev[i], 0));
@@ -1058,6 +1070,11 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
             HIPCHK(hipEventRecord(c->slice_ev[NS0 + i], c->copy_stream));
         }
         PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
+        if (k.sig) {
+            const int i = step >= NS0 ? step - NS0 : step;
+            HIPCHK(hipEventRecord(k.sig[i], sA));
+            if (k.sig_count) k.sig_count->store(i + 1, std::memory_order_release);
+        }
     }
     return PC_OK;
 }
@@ -1068,9 +1085,14 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     pc_codec* c = k.c;
     HIPCHK(hipSetDevice(c->device));
     const size_t pi = (size_t)k.HW, per = (size_t)SLICE * k.HW;
-    int32_t* h_idx = c->h_idx + (size_t)b0 * per;
-    int32_t* h_sym = c->h_sym + (size_t)b0 * per;
+    int32_t* h_idx = c->h_idx + k.h_off + (size_t)b0 * per;
+    int32_t* h_sym = c->h_sym + k.h_off + (size_t)b0 * per;
     for (int step = k.step0; step < k.step1; ++step) {
+        if (k.waitv) {                                                                   // pipelined against the other chain
+            const int i = step >= NS0 ? step - NS0 : step;
+            if (k.wait_count) while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+            HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
+        }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         const bool e = step >= NS0;
@@ -1090,6 +1112,11 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         PCCHK(pc_gc_dequantize(k.sym + so, k.mu + so, SLICE, nb, k.HW, dst, D0, sA));                                          // :896,971
         PCCHK(chain_lrp(k, step, b0, nb, sA, tag));
         // the H2D copy out of h_sym is ordered before the next step's host decode by that step's hipStreamSynchronize(sA)
+        if (k.sig) {
+            const int i = step >= NS0 ? step - NS0 : step;
+            HIPCHK(hipEventRecord(k.sig[i], sA));
+            if (k.sig_count) k.sig_count->store(i + 1, std::memory_order_release);
+        }
     }
     return PC_OK;
 }
@@ -1176,6 +1203,31 @@ int encode_streams(pc_codec* c, const int32_t* hs, const int32_t* hi, int first_
     return rc;
 }
 
+// Base chain || enhancement chain.  Enhancement slice i needs base slice i and the enhancement slices before it, nothing else
+// (CHProg_cnn.py:775-845: support = y_hat_slices[i] + y_hat_slices_quality[i-5:i]), so the two ten-step chains can run one slice
+// apart on two streams over the WHOLE batch: the N = 64 / 32 tail layers of one chain fill the CUs the other leaves idle, and in
+// the decoder one chain's host rANS round trip hides behind the other chain's kernels -- without halving M as batch lanes do.
+bool pipeline_enabled(const pc_codec* c)
+{
+    static const bool on = [] { const char* v = std::getenv("PC_PIPELINE"); return !v || std::atoi(v) != 0; }();
+    return on && !c->profile;
+}
+
+int ensure_pipeline(pc_codec* c, size_t M)
+{
+    if (!c->pipe_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->pipe_stream, hipStreamNonBlocking));
+        c->pipe_ev.resize(NS0 + 2);
+        for (auto& e : c->pipe_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    float* dummy;                                     // both chains' stack workspaces, allocated up front
+    for (const char* tag : {"s5mPA", "s5sPA", "s5mPB", "s5sPB"}) {
+        PCCHK(c->buf(std::string(tag) + "_t0", M * 224, &dummy));
+        PCCHK(c->buf(std::string(tag) + "_t1", M * 176, &dummy));
+    }
+    return PC_OK;
+}
+
 // compress() for a list of mask levels.  Everything that does not depend on the level -- g_a, h_a, the hyper-latent
 // strings, h_s and the ten base slices (CHProg_cnn.py:692-767) -- runs once; the enhancement chain (:775-845) runs once per
 // level with quality > 0.  The GPU always has the next pass queued while the host entropy-codes the previous one:
@@ -1238,12 +1290,54 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     PCCHK(h_a(c, st, k.y, B, h, w, z));                                                  // :700
     PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :702-704
     PCCHK(hyper(c, st, z_hat, B, zh, zw, any_enh ? 1.0 : 0.0, k.lm, k.ls));              // :705-715
-    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
-    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :729-767
-    HIPCHK(hipMemcpyAsync(c->h_sym, k.sym, n_half * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_half * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(c->h_sym + 3 * n_half, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipEventRecord(c->lvl_events[0], st));
+    // The LAST coded level has no later GPU pass to hide its entropy coding behind: with a single encoder lane its slices are copied
+    // out one by one (side stream) and coded while the rest of the chain still runs; only the last slice's coding is exposed.
+    int last_coded = -1, first_coded = -1;
+    for (int l = 0; l < n_levels; ++l) if (!(qualities[l] <= 0)) { last_coded = l; if (first_coded < 0) first_coded = l; }
+    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return v && std::atoi(v) != 0; }();
+    const bool can_stream = !no_stream && lane_count(c, B, false) == 1;
+    if (can_stream && !c->copy_stream) {
+        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        c->slice_ev.resize(2 * NS0);
+        for (auto& e : c->slice_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    auto base_d2h = [&]() -> int {
+        HIPCHK(hipMemcpyAsync(c->h_sym, k.sym, n_half * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(c->h_idx, k.idx, n_half * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(c->h_sym + 3 * n_half, z_sym, n_z * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(c->lvl_events[0], st));
+        return PC_OK;
+    };
+    const bool piped = pipeline_enabled(c) && first_coded >= 0 && lane_count(c, B, false) == 1;
+    if (piped) {
+        // base slice t on `st`, enhancement slice t-1 of the first coded level on pipe_stream, enqueued alternately
+        PCCHK(ensure_pipeline(c, M));
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0], st));
+        HIPCHK(hipStreamWaitEvent(c->pipe_stream, c->pipe_ev[NS0], 0));
+        ChainCtx kb = k, ke = k;
+        kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data();
+        ke.enh = true; ke.level = first_coded; ke.waitv = c->pipe_ev.data();
+        ke.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[first_coded], &ke.q);
+        ke.masks = masks_out ? masks_out[first_coded] : nullptr;
+        if (can_stream && first_coded == last_coded) { ke.so_sym = c->h_sym + n_half; ke.so_idx = c->h_idx + n_half; }
+        for (int t = 0; t <= NS0; ++t) {
+            if (t < NS0) {
+                kb.step0 = t; kb.step1 = t + 1;
+                PCCHK(encode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA"));                // :729-767
+                if (t == NS0 - 1) PCCHK(base_d2h());
+            }
+            if (t >= 1) {
+                ke.step0 = NS0 + t - 1; ke.step1 = NS0 + t;
+                PCCHK(encode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB"));   // :775-845
+            }
+        }
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+    } else {
+        k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :729-767
+        PCCHK(base_d2h());
+    }
 
     // what the host still has to entropy-code once its event has fired: -1 = base + z, else the level index
     int pending = -1, pending_buf = 0, n_coded = 0;
@@ -1267,17 +1361,6 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         t_enc_last = now() - te;                             // pure host rANS time of this pass (the last one is not overlapped)
         return r;
     };
-    // The LAST coded level has no later GPU pass to hide its entropy coding behind: with a single encoder lane its slices are copied
-    // out one by one (side stream) and coded while the rest of the chain still runs; only the last slice's coding is exposed.
-    int last_coded = -1;
-    for (int l = 0; l < n_levels; ++l) if (!(qualities[l] <= 0)) last_coded = l;
-    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return v && std::atoi(v) != 0; }();
-    const bool can_stream = !no_stream && lane_count(c, B, false) == 1;
-    if (can_stream && !c->copy_stream) {
-        HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        c->slice_ev.resize(2 * NS0);
-        for (auto& e : c->slice_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    }
     for (int l = 0; l < n_levels; ++l) {
         if (qualities[l] <= 0) continue;                                                 // base only: nothing level-specific to code
         k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
@@ -1285,10 +1368,13 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         k.masks = masks_out ? masks_out[l] : nullptr;
         const int bufsel = n_coded & 1;
         const size_t off = (size_t)(1 + bufsel) * n_half;
+        const bool pre = piped && l == first_coded;                                      // already enqueued, pipelined with the base chain
         if (can_stream && l == last_coded) {
-            k.so_sym = c->h_sym + off; k.so_idx = c->h_idx + off;
-            PCCHK(run_chain(k, st, false, nullptr, nullptr));                            // :775-845, slices streamed out
-            k.so_sym = k.so_idx = nullptr;
+            if (!pre) {
+                k.so_sym = c->h_sym + off; k.so_idx = c->h_idx + off;
+                PCCHK(run_chain(k, st, false, nullptr, nullptr));                        // :775-845, slices streamed out
+                k.so_sym = k.so_idx = nullptr;
+            }
             c->res_level_coded[l] = 1;
             ++n_coded;
             int r = drain(pending, pending_buf);                                         // the pass before, meanwhile
@@ -1306,7 +1392,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
             t_host += now() - te;
             continue;
         }
-        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :775-845
+        if (!pre) PCCHK(run_chain(k, st, false, nullptr, nullptr));                      // :775-845
         HIPCHK(hipMemcpyAsync(c->h_sym + off, k.sym + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(c->h_idx + off, k.idx + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipEventRecord(c->lvl_events[1 + l], st));
