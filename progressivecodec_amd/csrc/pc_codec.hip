@@ -1039,7 +1039,10 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     for (int step = k.step0; step < k.step1; ++step) {
         if (k.waitv) {                                                                   // pipelined against the other chain
             const int i = step >= NS0 ? step - NS0 : step;
-            if (k.wait_count) while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+            if (k.wait_count) {
+                while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+                if (k.wait_count->load(std::memory_order_acquire) >= (1 << 20)) return PC_ERR_STATE;    // the other chain failed
+            }
             HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
         }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
@@ -1090,7 +1093,10 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     for (int step = k.step0; step < k.step1; ++step) {
         if (k.waitv) {                                                                   // pipelined against the other chain
             const int i = step >= NS0 ? step - NS0 : step;
-            if (k.wait_count) while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+            if (k.wait_count) {
+                while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
+                if (k.wait_count->load(std::memory_order_acquire) >= (1 << 20)) return PC_ERR_STATE;    // the other chain failed
+            }
             HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
         }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
@@ -1574,8 +1580,38 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     HIPCHK(hipStreamSynchronize(st));   // h_sym is reused by the lanes
     PCCHK(hyper(c, st, z_hat, B, zh, zw, any_enh ? 1.0 : 0.0, k.lm, k.ls));              // :856-867
     c->t_host_decode_ms = 0.0;
-    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
-    PCCHK(run_chain(k, st, true, y_strings, y_lens));                                    // :874-904
+    int first_enh = -1;
+    for (int l = 0; l < n_levels && first_enh < 0; ++l) if (qualities[l] != 0) first_enh = l;
+    static const bool pipe_dec = [] { const char* v = std::getenv("PC_PIPELINE_DEC"); return !v || std::atoi(v) != 0; }();
+    const bool piped = pipeline_enabled(c) && pipe_dec && first_enh >= 0;
+    if (piped) {
+        // base chain on `st` (own host thread) || enhancement chain of the first coded level on pipe_stream (this thread), one slice
+        // apart: each chain's host rANS round trip hides behind the other chain's kernels, at full M
+        PCCHK(ensure_pipeline(c, M));
+        PCCHK(ensure_host_staging(c, std::max(2 * per * B, per_z * B)));
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0], st));
+        HIPCHK(hipStreamWaitEvent(c->pipe_stream, c->pipe_ev[NS0], 0));
+        std::atomic<int> recorded{0};
+        ChainCtx kb = k, ke = k;
+        kb.step0 = 0; kb.step1 = NS0; kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data(); kb.sig_count = &recorded; kb.h_off = 0;
+        ke.step0 = NS0; ke.step1 = 2 * NS0; ke.enh = true; ke.level = first_enh; ke.waitv = c->pipe_ev.data(); ke.wait_count = &recorded;
+        ke.h_off = per * B;
+        ke.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[first_enh], &ke.q);
+        int rb = PC_OK;
+        std::thread tb([&] {
+            rb = decode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt);                  // :874-904
+            if (rb != PC_OK) recorded.store(1 << 20, std::memory_order_release);                               // release the other chain
+        });
+        const int re = decode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB", y_strings, y_lens, nt);   // :930-983
+        tb.join();
+        if (rb != PC_OK) return rb;
+        if (re != PC_OK) return re;
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+    } else {
+        k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+        PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :874-904
+    }
     const size_t img_elems = (size_t)B * 3 * (16 * h) * (16 * w);
     for (int l = 0; l < n_levels; ++l) {
         float* out = x_hat + (size_t)l * img_elems;
@@ -1583,9 +1619,11 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
             PCCHK(g_s(c, st, c->gs[0], k.yb, B, h, w, out));                             // :907-916
             continue;
         }
-        k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
-        k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);
-        PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :930-983
+        if (!(piped && l == first_enh)) {
+            k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
+            k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);
+            PCCHK(run_chain(k, st, true, y_strings, y_lens));                            // :930-983
+        }
         PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990
     }
     if (std::getenv("PC_TIMING")) std::fprintf(stderr, "[pcodec] decompress: %d level(s), host rANS decode (summed over lanes) %.2f ms\n", n_levels, c->t_host_decode_ms);
