@@ -1517,13 +1517,30 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
     PCCHK(pc_eb_quant_launch(z, B, ZHW, NCH, c->medians, z_sym, z_hat, st));             // :401-403
     PCCHK(pc_eb_likelihood_launch(z_sym, B, ZHW, NCH, c->medians, c->eb_net, z_lik, st));   // :400
     PCCHK(hyper(c, st, z_hat, B, zh, zw, enh ? 1.0 : 0.0, k.lm, k.ls));                  // :404-417
-    k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
-    PCCHK(run_chain(k, st, false, nullptr, nullptr));                                    // :1033-1061
-    if (enh) {
-        k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = 0;
-        k.mode = mask_mode_for(mask_pol, quality, &k.q);
-        k.masks = masks_out;
-        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :1089-1160
+    if (enh && pipeline_enabled(c) && lane_count(c, B, false) == 1) {
+        // base slice t || enhancement slice t-1, as in compress_impl
+        PCCHK(ensure_pipeline(c, M));
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0], st));
+        HIPCHK(hipStreamWaitEvent(c->pipe_stream, c->pipe_ev[NS0], 0));
+        ChainCtx kb = k, ke = k;
+        kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data();
+        ke.enh = true; ke.level = 0; ke.waitv = c->pipe_ev.data(); ke.masks = masks_out;
+        ke.mode = mask_mode_for(mask_pol, quality, &ke.q);
+        for (int t = 0; t <= NS0; ++t) {
+            if (t < NS0) { kb.step0 = t; kb.step1 = t + 1; PCCHK(encode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA")); }                       // :1033-1061
+            if (t >= 1) { ke.step0 = NS0 + t - 1; ke.step1 = NS0 + t; PCCHK(encode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB")); }   // :1089-1160
+        }
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+    } else {
+        k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
+        PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :1033-1061
+        if (enh) {
+            k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = 0;
+            k.mode = mask_mode_for(mask_pol, quality, &k.q);
+            k.masks = masks_out;
+            PCCHK(run_chain(k, st, false, nullptr, nullptr));                            // :1089-1160
+        }
     }
     PCCHK(g_s(c, st, c->gs[enh ? 1 : 0], enh ? k.ye : k.yb, B, h, w, x_hat));            // :1065 / :1166-1170
     return PC_OK;
