@@ -584,25 +584,49 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     if (STAMPS) { t_epi = __builtin_amdgcn_s_memtime(); r_epi = __builtin_amdgcn_s_memrealtime(); }
     if (!live) return;
     const int n = n0 + wn * 32 + l31;
-    if (n >= p.Cout) return;
-    const float bv = bias ? bias[n] : 0.0f;
+    const float bv = (bias && n < p.Cout) ? bias[n] : 0.0f;
     if (p.dense_out) {
         // layers storing a plain NHWC(-strided) tensor on the GEMM's own pixel grid: the output pixel index is the GEMM row, no
-        // div/mod.  (Loading the 16 aux elements of a lane up front as independent loads was tried: +32 VGPRs cost occupancy
-        // and the 16x unrolled GELU code; GDN and the 1x1 layers got 8-16 % slower, profiles/r01_j_*.)
+        // div/mod.  The epilogue's aux tiles (residual / gate / GDN input / LRP base: 32 rows x 32 columns per wave) are fetched with
+        // four LDS-DMA loads per tile into the now idle stage buffers and read back from LDS: one memory latency per wave instead
+        // of a chain of 16 dependent global loads (the epilogue of the 1x1 layers was 3x its VALU and HBM bounds), and no extra
+        // VGPRs (holding the 16 values in registers cost occupancy: profiles/r01_j_*).
+        const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
+        float* tile = reinterpret_cast<float*>(smem + wave * 512);            // 2 x 4 KB per MFMA wave (S * STAGE >= 2048 float4)
+        if (u0) {
+            constexpr int OOBE = (int)0x80000000;
+            const int mb = m0 + wm * 32, nb = n0 + wn * 32;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                if (a == 1 && !u1) break;
+                const float* src = (a == 0 ? p.aux0 : p.aux1) + (int64_t)mb * (a == 0 ? p.ld0 : p.ld1) + nb;
+                const int ld = a == 0 ? p.ld0 : p.ld1;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int piece = i * 64 + lane, row = piece >> 3, cq = piece & 7;
+                    const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + i * 256), 16,
+                                                             ok ? (row * ld + 4 * cq) * 4 : OOBE, 0, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (n >= p.Cout) return;                              // (only now: the tile loads above need the whole wave)
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = m0 + wm * 32 + row;
             if (m >= p.M) continue;
             float v = acc[r];
             if (bias) v = v + bv;
-            v = epilogue_value(p, v, (int64_t)m, n);
-            outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = v;
+            const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
+            outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
         }
     } else
     for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
         const int m = m0 + wm * 32 + row;
-        if (m >= p.M) continue;
+        if (m >= p.M || n >= p.Cout) continue;
         const int b = m / HoWo, rr = m - b * HoWo;
         const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
         const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
