@@ -178,7 +178,7 @@ def main():
         "roofline": roofline,
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (bench contract)
         # CPU baseline: the oracle port (same ATen CPU op sequence as the reference, bit-identical strings on one
         # machine -- tests/test_oracle_vs_golden.py), on a bounded sample of the same workload.
         from oracle.codec_ref import RefCodec
