@@ -395,6 +395,17 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
                 a_rel[i] = ok ? p.rowtab[m] - (int)pix0 : 0;
                 a_mask[i] = (ok && !(p.dbg & 4)) ? (uint32_t)p.rowtab[(size_t)(1 + phase) * p.M + m] : 0u;
             }
+        } else if (p.ident_rows) {
+            // 1x1 stride-1 layers (linear, GDN, the ResidualUnit 1x1s): row m of the GEMM is input pixel m, the single tap is always valid
+            pix0 = m0;
+#pragma unroll
+            for (int i = 0; i < AIN; ++i) {
+                const int pa = (lw * AIN + i) * 64 + lane;
+                const int row = pa / KQ, slot = pa % KQ;
+                a_q[i] = slot ^ pc_swz<KQ>(row);
+                a_rel[i] = row;
+                a_mask[i] = (m0 + row < p.M && !(p.dbg & 4)) ? 1u : 0u;
+            }
         } else {
             {
                 const int b = m0 / HoWo, r = m0 - b * HoWo;
@@ -758,6 +769,8 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         static const bool no_tab = [] { const char* v = std::getenv("PC_CONV_NO_ROWTAB"); return v && std::atoi(v) != 0; }();
         const_cast<pc_conv_params&>(p).rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
     }
+    const_cast<pc_conv_params&>(p).ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
+                                                p.Ho == p.H && p.Wo == p.W;
     const_cast<pc_conv_params&>(p).dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&
                                                p.outW == p.Wo && !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx &&
                                                p.out_sb == (int64_t)p.outH * p.out_sy;

@@ -68,6 +68,7 @@ struct pc_conv_params {
     const float* g1_seg0; const float* g1_w; const float* g1_bias; float* g1_out;
     const int* rowtab;                       // set by pc_conv_launch (layers with more than one tap): cached per layer geometry,
                                              // [M] input-pixel index of each GEMM row, then [nphase][M] tap-validity masks
+    int ident_rows;                          // set by pc_conv_launch: 1x1 stride-1 layer, GEMM row m reads input pixel m (no row table)
     int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
     int dbg;                                 // tuning only (PC_CONV_DBG bits): 1 skip MFMAs, 2 skip DMA issue, 4 DMAs read the zero page, 64 stamps, 256 print occupancy
 };
