@@ -43,8 +43,26 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
         return ((int64_t)b * H + y) * W + x;
     };
 
+    // G == 1 (8x8 windows): the wave's 64 lanes are the 64 tokens of ONE (window, head) pair.  Every lane needs every token's k and
+    // v: staged once in LDS (each lane writes its own token's two vectors) and read back as broadcasts, instead of 2 x 64 x D/4
+    // same-address vector loads per lane from L1.  Same fmaf chains, same results.
+    constexpr int LDK = D + 4;                                 // padded row: 16-byte aligned, spreads the banks
+    __shared__ float kv_lds[G == 1 ? 4 * 2 * T * LDK : 1];
+    float* k_lds = kv_lds + (G == 1 ? wave * 2 * T * LDK : 0);
+    float* v_lds = k_lds + (G == 1 ? T * LDK : 0);
+
     int reg_i;
     const int64_t pix_i = token(i, reg_i);
+    if (G == 1) {
+        const float4* kp = reinterpret_cast<const float4*>(qkv + pix_i * C3 + C + h * D);
+        const float4* vp = reinterpret_cast<const float4*>(qkv + pix_i * C3 + 2 * C + h * D);
+#pragma unroll
+        for (int e = 0; e < D / 4; ++e) {
+            *reinterpret_cast<float4*>(k_lds + i * LDK + 4 * e) = kp[e];
+            *reinterpret_cast<float4*>(v_lds + i * LDK + 4 * e) = vp[e];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     float q[D];
     {
         const float4* qp = reinterpret_cast<const float4*>(qkv + pix_i * C3 + h * D);
@@ -60,7 +78,7 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
     for (int j = 0; j < T; ++j) {
         int reg_j;
         const int64_t pix_j = token(j, reg_j);
-        const float4* kp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + C + h * D);
+        const float4* kp = G == 1 ? reinterpret_cast<const float4*>(k_lds + j * LDK) : reinterpret_cast<const float4*>(qkv + pix_j * C3 + C + h * D);
         float acc = 0.0f;
 #pragma unroll
         for (int e = 0; e < D / 4; ++e) {
@@ -87,7 +105,7 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
     for (int j = 0; j < T; ++j) {
         int reg_j;
         const int64_t pix_j = token(j, reg_j);
-        const float4* vp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + 2 * C + h * D);
+        const float4* vp = G == 1 ? reinterpret_cast<const float4*>(v_lds + j * LDK) : reinterpret_cast<const float4*>(qkv + pix_j * C3 + 2 * C + h * D);
 #pragma unroll
         for (int e = 0; e < D / 4; ++e) {
             const float4 v = vp[e];
