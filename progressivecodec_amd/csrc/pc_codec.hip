@@ -89,6 +89,8 @@ struct pc_codec {
     std::vector<hipEvent_t> lvl_events;           // D2H completion of the base pass / of each level
     hipStream_t copy_stream = nullptr;            // per-slice D2H of the last pass (streamed entropy coding)
     hipStream_t pipe_stream = nullptr;            // enhancement chain when it is pipelined against the base chain
+    hipStream_t hyper_streams[3] = {nullptr, nullptr, nullptr};   // the four hyper-synthesis nets run side by side
+    hipEvent_t hyper_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> pipe_ev;              // [NS0] base slice i complete, [NS0] pipeline fork, [NS0+1] pipeline join
     std::vector<hipEvent_t> slice_ev;             // [2*NS0]: prep done / copied, per slice of that pass
     std::vector<std::vector<uint8_t>> y_strings;  // [slot*B + b]; slot = slice (base) or 10 + 10*level + (slice - 10)
@@ -466,14 +468,14 @@ int stack5_pair(pc_codec* c, hipStream_t st, const Stack5W& sm, const Stack5W& s
 }
 
 // hyper-synthesis net (CHProg_cnn.py:208-232): z_hat [B][zh][zw][192] -> out slice [B][4zh][4zw][320] (ld 640)
-int hs(pc_codec* c, hipStream_t st, const HsW& h, const float* z, int B, int zh, int zw, float* out, int ldo)
+int hs(pc_codec* c, hipStream_t st, const HsW& h, const float* z, int B, int zh, int zw, float* out, int ldo, const char* tag = "")
 {
     const size_t M = (size_t)B * zh * zw;
     float *t0, *t1, *t2, *t3;
-    PCCHK(c->buf("hs_t0", M * 192, &t0));
-    PCCHK(c->buf("hs_t1", M * 4 * 224, &t1));
-    PCCHK(c->buf("hs_t2", M * 4 * 256, &t2));
-    PCCHK(c->buf("hs_t3", M * 16 * 288, &t3));
+    PCCHK(c->buf(std::string("hs_t0") + tag, M * 192, &t0));
+    PCCHK(c->buf(std::string("hs_t1") + tag, M * 4 * 224, &t1));
+    PCCHK(c->buf(std::string("hs_t2") + tag, M * 4 * 256, &t2));
+    PCCHK(c->buf(std::string("hs_t3") + tag, M * 16 * 288, &t3));
     PCCHK(conv(st, h.c0, {{z, 192, 192}}, B, zh, zw, 1, t0, 192, PC_EPI_GELU));
     PCCHK(conv(st, h.c2, {{t0, 192, 192}}, B, zh, zw, 1, t1, 224, PC_EPI_GELU, nullptr, 0, nullptr, 0, true));
     PCCHK(conv(st, h.c4, {{t1, 224, 224}}, B, 2 * zh, 2 * zw, 1, t2, 256, PC_EPI_GELU));
@@ -590,11 +592,32 @@ int mask_mode_for(int mask_pol, double quality, float* q_out)
 
 int hyper(pc_codec* c, hipStream_t st, const float* z_hat, int B, int zh, int zw, double quality, float* lm, float* ls)
 {
-    PCCHK(hs(c, st, c->hss[0], z_hat, B, zh, zw, ls, MLAT));
-    PCCHK(hs(c, st, c->hms[0], z_hat, B, zh, zw, lm, MLAT));
-    if (quality != 0) {                       // CHProg_cnn.py:708-715
-        PCCHK(hs(c, st, c->hss[1], z_hat, B, zh, zw, ls + D0, MLAT));
-        PCCHK(hs(c, st, c->hms[1], z_hat, B, zh, zw, lm + D0, MLAT));
+    // h_scale_s[k] / h_mean_s[k] (CHProg_cnn.py:705-715) all read z_hat and nothing else: their first layers have ~110 workgroups
+    // each on 256 CUs, so the two (base only) or four nets run side by side on their own streams with their own workspaces.
+    static const bool par = [] { const char* v = std::getenv("PC_HYPER_PARALLEL"); return !v || std::atoi(v) != 0; }();
+    const int n = quality != 0 ? 4 : 2;
+    if (!par || c->profile) {
+        PCCHK(hs(c, st, c->hss[0], z_hat, B, zh, zw, ls, MLAT));
+        PCCHK(hs(c, st, c->hms[0], z_hat, B, zh, zw, lm, MLAT));
+        if (quality != 0) {                       // CHProg_cnn.py:708-715
+            PCCHK(hs(c, st, c->hss[1], z_hat, B, zh, zw, ls + D0, MLAT));
+            PCCHK(hs(c, st, c->hms[1], z_hat, B, zh, zw, lm + D0, MLAT));
+        }
+        return PC_OK;
+    }
+    if (!c->hyper_ev[0]) {
+        for (auto& sx : c->hyper_streams) HIPCHK(hipStreamCreateWithFlags(&sx, hipStreamNonBlocking));
+        for (auto& e : c->hyper_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    const HsW* nets[4] = {&c->hss[0], &c->hms[0], &c->hss[1], &c->hms[1]};
+    float* outs[4] = {ls, lm, ls + D0, lm + D0};
+    const char* tags[4] = {"", "_h1", "_h2", "_h3"};
+    HIPCHK(hipEventRecord(c->hyper_ev[0], st));                                         // fork: z_hat ready
+    for (int i = 0; i < n; ++i) {
+        hipStream_t sx = i == 0 ? st : c->hyper_streams[i - 1];
+        if (i > 0) HIPCHK(hipStreamWaitEvent(sx, c->hyper_ev[0], 0));
+        PCCHK(hs(c, sx, *nets[i], z_hat, B, zh, zw, outs[i], MLAT, tags[i]));
+        if (i > 0) { HIPCHK(hipEventRecord(c->hyper_ev[i], sx)); HIPCHK(hipStreamWaitEvent(st, c->hyper_ev[i], 0)); }   // join
     }
     return PC_OK;
 }
