@@ -780,6 +780,13 @@ extern "C" void pc_codec_destroy(pc_codec* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (auto& L : c->lanes) { (void)hipStreamDestroy(L.sA); (void)hipStreamDestroy(L.sB); (void)hipEventDestroy(L.eA); (void)hipEventDestroy(L.eB); (void)hipEventDestroy(L.eDone); }
     if (c->eFork) (void)hipEventDestroy(c->eFork);
+    for (hipEvent_t e : c->lvl_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->hyper_ev) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t sx : c->hyper_streams) if (sx) (void)hipStreamDestroy(sx);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->pipe_stream) (void)hipStreamDestroy(c->pipe_stream);
     if (c->h_sym) (void)hipHostFree(c->h_sym);
     if (c->h_idx) (void)hipHostFree(c->h_idx);
     delete c;
