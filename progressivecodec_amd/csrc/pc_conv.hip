@@ -277,9 +277,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // Wave-specialised kernel with LDS-DMA loaders (weight layout 1).  Ablations of the kernel above
 // (tools/conv_tune.py, PC_CONV_DBG): loader-only 111 us + MFMA-only 165 us ~= full 246 us on the
 // 8192x224x4608 slice-chain GEMM -- loader instructions and f32 MFMAs do not overlap on a SIMD, so
-// every loader instruction costs matrix time.  Here the loader waves issue only
-// `global_load_lds_dwordx4` (16 B per lane straight into LDS, no VGPR staging, no ds_write) plus a
-// few address ops; the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE
+// every loader instruction costs matrix time.  Here the loader waves issue only LDS-DMA loads
+// (`buffer_load_dwordx4 ... lds`: 16 B per lane straight into LDS, no VGPR staging, no ds_write) plus a
+// few scalar ops; the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE
 // address (LDS-DMA writes lane-linearly), read back conflict-free with ds_read_b128; weights are
 // pre-packed [tap][Cout][Cin] (K contiguous per output channel).  The contract's chain order inside an
 // aligned group of 8 k (0,4,1,5,2,6,3,7) is exactly what the MFMA computes when lanes 0-31 hold the
@@ -291,8 +291,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // `s_waitcnt vmcnt(N)`; raw `s_barrier`s, which do not drain VMEM, hand a landed stage to the MFMA waves),
 // WM x WN MFMA waves of one 32x32 tile each (block tile 32*WM x 32*WN) and as many loader waves.
 // ------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(64))) float pc_zero_page[16];
-// diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop phases, [block][8]
+// diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop / prologue / epilogue phases, [block][16]
 __device__ unsigned long long pc_dbg_stamps[8192][16];
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
