@@ -28,10 +28,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/pc_math.h"
@@ -295,6 +297,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 __device__ unsigned long long pc_dbg_stamps[8192][16];
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
 
@@ -656,6 +659,374 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
 #endif
 }
 
+// ------------------------------------------------------------------------------------------
+// Unified kernel (round 2): every wave loads AND multiplies; no loader waves.
+//
+// Why: a `buffer_load ... lds` instruction holds a SIMD's issue port for tens of cycles
+// (MI355X_MICROARCH.md: ~60 among bare MFMAs).  Issued by a separate loader wave at raised priority it
+// lands wherever the arbiter puts it -- often at the moment the matrix pipe drains, and the MFMA that
+// was ready waits behind it.  Issued by the MFMA wave itself, right AFTER one of its own MFMAs, the
+// DMA sits in that MFMA's 64-cycle shadow (the pipe is busy anyway, no other MFMA could start).
+// So: 256 threads = 4 waves (2 x 2), each wave owns TM x TN accumulator tiles of 32x32 (block tile
+// 64*TM x 64*TN) and a quarter of every chunk's LDS-DMA pieces, placed one by one behind MFMAs of the
+// chunk it is computing.  Larger wave tiles (TM, TN = 2) halve the L2->LDS bytes and the DMA / ds_read
+// instructions per FLOP.  LDS image, swizzle, run table, buffer-form addressing, XCD-aware tile order,
+// epilogues and -- above all -- each output element's fmaf chain are those of the kernel above.
+//
+// Pipeline (S stages, chunk c in stage c % S), one raw barrier per chunk:
+//   loop c:  s_waitcnt vmcnt(NI*(S-2))   my pieces of chunk c have landed (c+1 .. c+S-2 may be in flight)
+//            s_barrier                   everyone's have; everyone is done reading chunk c-1
+//            MFMAs of chunk c, with the NI pieces of chunk c+S-1 (into the stage chunk c-1 occupied) between them
+// ------------------------------------------------------------------------------------------
+template <int BK, int S, int TM, int TN, bool SQ>
+__global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_params p)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN, KQ = BK / 4;
+    constexpr int NTH = 256;
+    constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
+    constexpr int AIN = A_PIECES / NTH, BIN = B_PIECES / NTH, NI = AIN + BIN;   // DMA instructions per thread per chunk
+    constexpr int NG = BK / 8;                              // groups of 8 k = 4 MFMA steps per accumulator
+    constexpr int NSLOT = NG * 4 * TM * TN;                 // MFMAs per wave per chunk
+    static_assert(A_PIECES % NTH == 0 && B_PIECES % NTH == 0 && NI <= NSLOT, "tile / thread mismatch");
+    static_assert(S >= 2 && (S - 2) * NI < 64, "vmcnt range");
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ float4 smem[];                        // S stages, then the run table (launch_uni sizes it)
+
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // XCD-aware tile order: see conv_igemm_dma_kernel
+    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
+    const int mpx = (MT + 7) >> 3;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int m_local = slot / (NT * NZ), nz = slot - m_local * (NT * NZ);
+    const int m_tile = xcd * mpx + m_local;
+    if (m_tile >= MT) return;
+    const int zsel = nz / NT, n_tile = nz - zsel * NT;
+    int phase = zsel;
+    const float* seg0_ptr = p.seg[0].ptr;
+    const float* wbase = p.w;
+    const float* bias = p.bias;
+    float* outp = p.out;
+    if (p.ngroup == 2 && zsel == 1) { seg0_ptr = p.g1_seg0; wbase = p.g1_w; bias = p.g1_bias; outp = p.g1_out; }
+    if (p.ngroup == 2) phase = 0;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int T = p.ntap[phase];
+    const int HoWo = p.Ho * p.Wo;
+    int chunks_per_tap = 0;
+    for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
+    const int nchunks = T * chunks_per_tap;
+
+    // ---- this thread's DMA pieces: piece pa of the A image = (row pa / KQ, LDS slot pa % KQ) holds source k-quad slot ^ swz(row)
+    constexpr int OOB = (int)0x80000000;
+    int a_q[AIN], a_rel[AIN]; uint32_t a_mask[AIN];
+    int64_t pix0;
+    if (p.rowtab) {
+        pix0 = p.rowtab[m0];
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) {
+            const int pa = (wave * AIN + i) * 64 + lane;
+            const int row = pa / KQ, sl = pa % KQ;
+            a_q[i] = sl ^ pc_swz<KQ>(row);
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            a_rel[i] = ok ? p.rowtab[m] - (int)pix0 : 0;
+            a_mask[i] = ok ? (uint32_t)p.rowtab[(size_t)(1 + phase) * p.M + m] : 0u;
+        }
+    } else if (p.ident_rows) {
+        pix0 = m0;
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) {
+            const int pa = (wave * AIN + i) * 64 + lane;
+            const int row = pa / KQ, sl = pa % KQ;
+            a_q[i] = sl ^ pc_swz<KQ>(row);
+            a_rel[i] = row;
+            a_mask[i] = (m0 + row < p.M) ? 1u : 0u;
+        }
+    } else {
+        {
+            const int b = m0 / HoWo, r = m0 - b * HoWo;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            pix0 = ((int64_t)b * p.H + (int64_t)oy * p.stride) * p.W + (int64_t)ox * p.stride;
+        }
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) {
+            const int pa = (wave * AIN + i) * 64 + lane;
+            const int row = pa / KQ, sl = pa % KQ;
+            a_q[i] = sl ^ pc_swz<KQ>(row);
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : m0;
+            const int b = mm / HoWo, r = mm - b * HoWo;
+            const int oy = r / p.Wo, ox = r - oy * p.Wo;
+            const int iy0 = oy * p.stride, ix0 = ox * p.stride;
+            a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
+            uint32_t mask = 0;
+            for (int t = 0; t < T; ++t) {
+                const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+            }
+            a_mask[i] = ok ? mask : 0u;
+        }
+    }
+    int b_q[BIN], b_off[BIN];
+#pragma unroll
+    for (int i = 0; i < BIN; ++i) {
+        const int pb = (wave * BIN + i) * 64 + lane;
+        const int row = pb / KQ, sl = pb % KQ;
+        b_q[i] = sl ^ pc_swz<KQ>(row);
+        b_off[i] = (n0 + row < p.Cout) ? (row * p.Cin + 4 * b_q[i]) * 4 : OOB;
+    }
+    // ---- run table (one entry per (tap, input segment)), built once per block
+    pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
+    const int nruns = T * p.nseg;
+    for (int r = threadIdx.x; r < nruns; r += NTH) {
+        const int t = r / p.nseg, sg = r - t * p.nseg;
+        int cbase = 0;
+        for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
+        pc_run d;
+        d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
+        d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
+        d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
+        runs[r] = d;
+    }
+    __syncthreads();                                       // no DMA in flight yet: a plain barrier is fine
+    const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
+    uint32_t ra_lo = 0, ra_hi = 0, rb_lo = 0, rb_hi = 0;
+    int a_off[AIN];
+    int run = 0, c_left = 0, koff = 0;
+    auto enter_run = [&](int r) {                          // hand-written LDS reads: see conv_igemm_dma_kernel
+        u32x4 lo, hi;
+        asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(lo), "=&v"(hi) : "v"(runs_lds + (uint32_t)r * 32u) : "memory");
+        const uint64_t pa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.x);
+        const uint64_t pw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.z);
+        const int d_ld = __builtin_amdgcn_readfirstlane((int)hi.x), d_nch = __builtin_amdgcn_readfirstlane((int)hi.y);
+        const int d_tap = __builtin_amdgcn_readfirstlane((int)hi.z);
+        const float* d_a = reinterpret_cast<const float*>(pa) + pix0 * d_ld;
+        const float* d_w = reinterpret_cast<const float*>(pw) + (int64_t)n0 * p.Cin;
+        ra_lo = (uint32_t)(uintptr_t)d_a; ra_hi = (uint32_t)((uintptr_t)d_a >> 32);
+        rb_lo = (uint32_t)(uintptr_t)d_w; rb_hi = (uint32_t)((uintptr_t)d_w >> 32);
+        c_left = d_nch; koff = 0;
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) a_off[i] = ((a_mask[i] >> d_tap) & 1u) ? (a_rel[i] * d_ld + 4 * a_q[i]) * 4 : OOB;
+    };
+    enter_run(0);
+    auto mk = [](uint32_t lo, uint32_t hi) {
+        const uint64_t a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a), 0, 0x7fffffff, 0x00020000);
+    };
+    // state of the chunk being issued: effective per-piece offsets (a partial last chunk of a segment masks its absent quads)
+    int ea[AIN], eb[BIN];
+    auto prepare = [&]() {
+        const bool full = c_left >= BK;
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) ea[i] = (full || 4 * a_q[i] < c_left) ? a_off[i] : OOB;
+#pragma unroll
+        for (int i = 0; i < BIN; ++i) eb[i] = (full || 4 * b_q[i] < c_left) ? b_off[i] : OOB;
+    };
+    auto piece = [&](int q, int stage, const __amdgpu_buffer_rsrc_t& rsrc_a, const __amdgpu_buffer_rsrc_t& rsrc_b) {
+        float4* base = smem + stage * STAGE;
+        if (q < AIN)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(base + (wave * AIN + q) * 64), 16, ea[q < AIN ? q : 0], koff, 0, 0);
+        else
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(base + A_PIECES + (wave * BIN + (q - AIN)) * 64), 16,
+                                                     eb[q >= AIN ? q - AIN : 0], koff, 0, 0);
+    };
+    auto advance = [&]() {
+        koff += BK * 4;
+        c_left -= BK;
+        if (c_left <= 0 && ++run < nruns) enter_run(run);
+    };
+
+    // ---- MFMA side
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int am = wm * 32 * TM + l31, bn = wn * 32 * TN + l31;     // first A / B row of this lane (tile i / j adds 32 i / 32 j)
+    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);       // rows 32 apart share the swizzle
+    int nlive = 0;                                                    // column tiles of this wave inside Cout
+#pragma unroll
+    for (int j = 0; j < TN; ++j) nlive += (n0 + (wn * TN + j) * 32 < p.Cout) ? 1 : 0;
+    nlive = __builtin_amdgcn_readfirstlane(nlive);
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // Operand reads are hand-written ds_read_b128: behind a plain LDS load hipcc places `s_waitcnt vmcnt(0)` whenever the wave has an
+    // LDS-DMA in flight (it must assume the read aliases the DMA's destination), which would drain the prefetch pipeline at every
+    // read.  The stage being read was retired by the counted vmcnt + barrier at the top of the chunk; the DMAs in flight target
+    // another stage.  Per-lane byte addresses of the NG k-groups' pieces (stage 0), tiles by immediate offsets.
+    const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    uint32_t a_addr[NG], b_addr[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        a_addr[g] = smem_lds + (uint32_t)(am * KQ + ((2 * g + half) ^ a_swz)) * 16u;
+        b_addr[g] = smem_lds + (uint32_t)(A_PIECES + bn * KQ + ((2 * g + half) ^ b_swz)) * 16u;
+    }
+    // one chunk: NL live column tiles; ISSUE: place the NI pieces of the chunk being fetched behind MFMAs
+    auto chunk = [&](auto nl_tag, auto issue_tag, int st_c, int st_i) {
+        constexpr int NL = decltype(nl_tag)::value;
+        constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int NS = NG * 4 * TM * (NL > 0 ? NL : 1);           // MFMA slots of this variant
+        const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
+        if (ISSUE) prepare();
+        if (NL == 0) {                                                // a wave with no live column still loads its share
+            if (ISSUE) {
+#pragma unroll
+                for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
+            }
+            return;
+        }
+        const uint32_t st_off = (uint32_t)st_c * (uint32_t)(STAGE * 16);
+        f32x4 va[2][TM], vb[2][TN];
+        auto reads = [&](int g) {
+            const uint32_t aa = a_addr[g] + st_off, ba = b_addr[g] + st_off;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va[g & 1][i]) : "v"(aa), "n"(i * 32 * KQ * 16));
+#pragma unroll
+            for (int j = 0; j < NL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb[g & 1][j]) : "v"(ba), "n"(j * 32 * KQ * 16));
+        };
+        reads(0);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) reads(g + 1);
+            // wait for group g's operands only (the TM + NL reads of group g+1 just issued stay in flight); the operands are tied to
+            // the wait so that no MFMA using them can be scheduled above it
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (g + 1 < NG) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(va[g & 1][i]) : "n"(TM + NL));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[g & 1][i]));
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(vb[g & 1][j]));
+            __builtin_amdgcn_sched_barrier(0);
+            float xa[TM][4], xb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                f32x4 x = va[g & 1][i];
+                if (SQ) x = x * x;                                    // GDN feeds x^2 (gdn.py:56)
+                xa[i][0] = x.x; xa[i][1] = x.y; xa[i][2] = x.z; xa[i][3] = x.w;
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) { const f32x4 y = vb[g & 1][j]; xb[j][0] = y.x; xb[j][1] = y.y; xb[j][2] = y.z; xb[j][3] = y.w; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < NL; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i][s], xb[j][s], acc[i][j], 0, 0, 0);
+                        if (ISSUE) {
+                            const int slot_ix = ((g * 4 + s) * TM + i) * NL + j;      // compile-time after unrolling
+#pragma unroll
+                            for (int q = 0; q < NI; ++q)
+                                if ((q * NS) / NI == slot_ix) { __builtin_amdgcn_sched_barrier(0); piece(q, st_i, rsrc_a, rsrc_b); __builtin_amdgcn_sched_barrier(0); }
+                        }
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto kloop = [&](auto nl_tag) {
+        int st_c = 0, st_i = 0, issued = 0;
+        // prologue: chunks 0 .. S-2 in flight
+        for (; issued < S - 1 && issued < nchunks; ++issued) {
+            const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
+            prepare();
+#pragma unroll
+            for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
+            advance();
+            st_i = st_i + 1 == S ? 0 : st_i + 1;
+        }
+        const int n_main = nchunks - (S - 1);
+        int c = 0;
+        for (; c < n_main; ++c) {
+            pc_wait_vm<NI * (S - 2)>();
+            __builtin_amdgcn_s_barrier();
+            chunk(nl_tag, std::true_type{}, st_c, st_i);
+            advance();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_c = st_c + 1 == S ? 0 : st_c + 1;
+            st_i = st_i + 1 == S ? 0 : st_i + 1;
+        }
+        for (; c < nchunks; ++c) {                                    // the last S-1 chunks: nothing left to fetch
+            pc_wait_chunks<NI, S - 2>(nchunks - 1 - c);
+            __builtin_amdgcn_s_barrier();
+            chunk(nl_tag, std::false_type{}, st_c, st_i);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            st_c = st_c + 1 == S ? 0 : st_c + 1;
+        }
+    };
+    if (nlive == TN) kloop(std::integral_constant<int, TN>{});
+    else if (nlive == 0) kloop(std::integral_constant<int, 0>{});
+    else kloop(std::integral_constant<int, 1>{});                     // TN == 2 only
+    __builtin_amdgcn_s_barrier();                                     // every wave is done with the stages: the epilogue reuses them
+
+    // ---- epilogue, tile by tile
+    if (nlive == 0) return;
+    const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
+    float* tile = reinterpret_cast<float*>(smem + wave * 512);        // 2 x 4 KB per wave (S * STAGE >= 2048 float4)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            if (j >= nlive) continue;
+            const int mb = m0 + wm * 32 * TM + i * 32, nb = n0 + (wn * TN + j) * 32;
+            if (mb >= p.M) continue;
+            const int n = nb + l31;
+            const float bv = (bias && n < p.Cout) ? bias[n] : 0.0f;
+            if (p.dense_out) {
+                if (u0) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads of this region are complete
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+                        if (a == 1 && !u1) break;
+                        const float* src = (a == 0 ? p.aux0 : p.aux1) + (int64_t)mb * (a == 0 ? p.ld0 : p.ld1) + nb;
+                        const int ld = a == 0 ? p.ld0 : p.ld1;
+                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
+                            const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
+                                                                     ok ? (row * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
+                        }
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+                if (n < p.Cout) {
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int m = mb + row;
+                        if (m >= p.M) continue;
+                        float v = acc[i][j][r];
+                        if (bias) v = v + bv;
+                        const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
+                        outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
+                    }
+                }
+            } else {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int m = mb + row;
+                    if (m >= p.M || n >= p.Cout) continue;
+                    const int b = m / HoWo, rr = m - b * HoWo;
+                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                    const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
+                    float v = acc[i][j][r];
+                    if (bias) v = v + bv;
+                    int nn = n, YY = Y, XX = X;
+                    if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
+                    const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
+                    v = epilogue_value(p, v, pix, nn);
+                    outp[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
+                }
+            }
+        }
+#endif
+}
+
 // ---- per-geometry row tables of the LDS-DMA kernel (see its prologue) ----
 __global__ void conv_rowtab_kernel(const pc_conv_params p, int* __restrict__ tab)
 {
@@ -718,19 +1089,50 @@ hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
     dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);       // 1-D: the kernel maps workgroup id -> (XCD band, M tile, N tile, phase/group)
     const bool stamps = (p.dbg & 64) != 0;
     auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true, SQ> : conv_igemm_dma_kernel<BK, S, WM, WN, false, SQ>;
-    static bool attr_set[2] = {false, false};             // per instantiation: allow more than 64 KB of dynamic LDS
-    if (lds > 48 * 1024 && !attr_set[stamps]) {
+    static std::atomic<uint32_t> attr_set[2];             // per instantiation, bit per device: more than 64 KB of dynamic LDS allowed
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && !(attr_set[stamps].load(std::memory_order_acquire) & (1u << (dev & 31)))) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
             return hipGetLastError();
-        attr_set[stamps] = true;
+        attr_set[stamps].fetch_or(1u << (dev & 31), std::memory_order_release);
     }
-    if (p.dbg & 256) {
+    static std::atomic<int> printed{0};
+    if ((p.dbg & 256) && printed.fetch_add(1) == 0) {
         int nb = -1;
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 128 * WM * WN, lds);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 128 * WM * WN, lds);
         fprintf(stderr, "[pc_conv] dma<%d,%d,%d,%d> grid %u x %u x %u, lds %zu B, max active blocks per CU %d\n", BK, S, WM, WN, grid.x, grid.y,
                 grid.z, lds, nb);
     }
     hipLaunchKernelGGL(kern, grid, dim3(128 * WM * WN), lds, stream, p);
+    return hipGetLastError();
+}
+
+template <int BK, int S, int TM, int TN, bool SQ = false>
+hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
+{
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    int tmax = 0;
+    for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
+    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
+    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
+    dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);
+    auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ>;
+    static std::atomic<uint32_t> attr_set{0};             // bit per device: more than 64 KB of dynamic LDS allowed for this instantiation
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (lds > 48 * 1024 && !(attr_set.load(std::memory_order_acquire) & (1u << (dev & 31)))) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
+            return hipGetLastError();
+        attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
+    }
+    static std::atomic<int> printed{0};
+    if ((p.dbg & 256) && printed.fetch_add(1) == 0) {
+        int nb = -1;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 256, lds);
+        fprintf(stderr, "[pc_conv] uni<%d,%d,%d,%d> grid %u, lds %zu B, max active blocks per CU %d\n", BK, S, TM, TN, grid.x, lds, nb);
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -810,8 +1212,21 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         }
         const int bk = bk_env ? bk_env : 32;
         const int S = s_env ? s_env : (chunks <= 8 ? 2 : 3);   // 1x1 layers with K <= 256: two stages (nothing to keep in flight)
+        // kernel family: 0 = wave-specialised (round 1), 1 = unified (every wave loads and multiplies)
+        static const int kern_env = [] { const char* v = std::getenv("PC_CONV_KERN"); return v ? std::atoi(v) : 1; }();
+        static const int tm_env = [] { const char* v = std::getenv("PC_CONV_TM"); return v ? std::atoi(v) : 0; }();
+        static const int tn_env = [] { const char* v = std::getenv("PC_CONV_TN"); return v ? std::atoi(v) : 0; }();
         e = hipErrorInvalidValue;
-        if (p.square) e = launch_dma<32, 2, 2, 2, true>(p, stream);        // GDN / IGDN: K = C <= 320
+        if (kern_env == 1) {
+            int tm = tm_env ? tm_env : 1, tn = tn_env ? tn_env : 1;
+            const int Su = s_env ? s_env : (chunks <= 8 ? 2 : 3);
+            if (p.square) e = launch_uni<32, 2, 1, 1, true>(p, stream);
+#define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
+            PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
+            PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2)
+#undef PC_UNI_CASE
+        }
+        else if (p.square) e = launch_dma<32, 2, 2, 2, true>(p, stream);        // GDN / IGDN: K = C <= 320
 #define PC_DMA_CASE(BK_, S_) else if (bk == BK_ && S == S_) e = launch_dma<BK_, S_, 2, 2>(p, stream);
         PC_DMA_CASE(32, 3) PC_DMA_CASE(32, 2) PC_DMA_CASE(32, 4) PC_DMA_CASE(64, 2) PC_DMA_CASE(64, 3)
 #undef PC_DMA_CASE

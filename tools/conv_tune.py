@@ -32,6 +32,14 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
     ("ru_1x1", 32, 64, 64, 96, 192, 1, 1),
     ("gdn_like", 32, 128, 128, 192, 192, 1, 1),
     ("ga_conv4", 32, 32, 32, 192, 640, 5, 2),
+    ("ga_conv3", 32, 64, 64, 192, 192, 5, 2),
+    ("ru_1x1a", 32, 64, 64, 192, 96, 1, 1),
+    ("qkv", 32, 64, 64, 192, 576, 1, 1),
+    ("wam16_3x3", 32, 16, 16, 320, 320, 3, 1),
+    ("wam16_1x1", 32, 16, 16, 640, 320, 1, 1),
+    ("ha_0", 32, 16, 16, 640, 320, 3, 1),
+    ("gs_d6", 32, 64, 64, 192, 192, 5, -1),      # stride -1: ConvTranspose2d(5, s2) in four phases
+    ("gs_d3", 32, 32, 32, 192, 192, 5, -1),
 ]
 
 
@@ -46,13 +54,19 @@ def main():
         x = torch.from_numpy(rng.standard_normal((B, H, W, ci)).astype(np.float32)).cuda()
         w = torch.from_numpy((rng.standard_normal((k * k, ci, co)) * 0.05).astype(np.float32)).cuda()
         b = torch.zeros(co, device="cuda")
-        Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+        kind = 0
+        if s < 0:
+            kind, s = 1, 1
+            Ho, Wo = 2 * H, 2 * W
+            flops = 2.0 * B * H * W * co * k * k * ci
+        else:
+            Ho, Wo = (H + 2 * (k // 2) - k) // s + 1, (W + 2 * (k // 2) - k) // s + 1
+            flops = 2.0 * B * Ho * Wo * co * k * k * ci
         out = torch.empty((B, Ho, Wo, co), device="cuda")
-        flops = 2.0 * B * Ho * Wo * co * k * k * ci
         P = lambda t: C.c_void_p(t.data_ptr())
         for cfg in cfgs:
             def run():
-                check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), 0, co, k, s, 0, cfg, P(out), None))
+                check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), kind, co, k, s, 0, cfg, P(out), None))
             try:
                 run()
             except Exception as e:
