@@ -66,6 +66,18 @@ PC_API int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encoded_le
                                        const int32_t* cdf_sizes, const int32_t* offsets,
                                        int32_t* symbols_out);
 
+/* Replaces compressai.ans.RansDecoder.set_stream + decode_stream (rans_interface.cpp:277-350): one stream decoded in several calls
+ * (each with its own indexes / tables).  `state` is two uint64 owned by the caller: zero both before the first call on a stream (that
+ * call reads the stream's initial state, as set_stream does); every successful call advances them.  The reference keeps this state
+ * inside the decoder object; here it stays with the caller so the function is re-entrant.
+ * compressai.ans.BufferedRansEncoder (encode_with_indexes ... flush, rans_interface.cpp:99-191) needs no entry point of its own:
+ * its output is by construction that of ONE pc_rans_encode_with_indexes call over the concatenated symbols / indexes. */
+PC_API int pc_rans_decode_stream(const uint8_t* encoded, size_t encoded_len, uint64_t* state,
+                                 const int32_t* indexes, size_t n,
+                                 const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                 const int32_t* cdf_sizes, const int32_t* offsets,
+                                 int32_t* symbols_out);
+
 /* Batched forms: n_streams independent streams of n symbols each (one per image, as the loop at
  * entropy_models.py:227-235 / :276-286 produces), coded on a host thread pool.
  * symbols/indexes: [n_streams][n].  Encode writes stream s at out + s*out_stride. */
@@ -147,9 +159,17 @@ PC_API int pc_codec_set_tensor(pc_codec* c, const char* name, const void* data, 
 PC_API int pc_codec_set_tables(pc_codec* c, int which /*0 = gaussian_conditional, 1 = entropy_bottleneck*/,
                                const int32_t* cdf, int n_cdf, int cdf_stride, const int32_t* cdf_sizes,
                                const int32_t* offsets);
+/* update(scale_table=...) (models/cnn.py:137-142 -> GaussianConditional.update_scale_table, entropy_models.py:588-597): replace the
+ * table of scales build_indexes searches (2..64 ascending floats, host pointer); set the matching CDFs with pc_codec_set_tables.
+ * Only after pc_codec_finalize. */
+PC_API int pc_codec_set_scale_table(pc_codec* c, const float* table, int n);
 /* Validate that every tensor is present, fold the GDN re-parametrisation, pack weights into HBM. */
 PC_API int pc_codec_finalize(pc_codec* c);
 PC_API int pc_codec_set_threads(pc_codec* c, int n_threads);
+/* How the host entropy-coding pool of this process is laid out: threads = min(16, CPUs allowed by affinity and cgroup quota / local ranks),
+ * pinned -- when there are several local ranks (LOCAL_WORLD_SIZE / LOCAL_RANK) -- to this rank's contiguous slice of the allowed CPUs
+ * starting at first_cpu.  No reference counterpart (the reference codes on one thread under the GIL, entropy_models.py:226-235). */
+PC_API int pc_host_pool_plan(int* n_threads, int* first_cpu, int* n_allowed);
 
 /* compress (models/CHProg_cnn.py:686-847).  x: device, NCHW [B][3][H][W], H and W multiples of 64.
  * On success the codec holds n_slices*B + B byte strings (n_slices = 10 for quality <= 0, else 20) until
@@ -191,10 +211,10 @@ PC_API int pc_codec_decompress_levels(pc_codec* c, const uint8_t* const* y_strin
 
 /* Bulk string transfer (binding overhead: 672 strings per Config-2 batch).  After a compress: _strings_size gives the total byte count
  * and the number of strings (all y slots, images inside a slot, then the z strings); _copy_strings concatenates them into dst (cap bytes)
- * and writes their lengths.  _decompress_packed takes the same layout: y strings of slots 0 .. 10+10*n_levels-1 (B each; empty strings
+ * and writes their lengths (lens_cap = entries available in lens; PC_ERR_BUFFER if either buffer is too small).  _decompress_packed takes the same layout: y strings of slots 0 .. 10+10*n_levels-1 (B each; empty strings
  * for the slots of quality-0 levels), then B z strings. */
 PC_API int pc_codec_strings_size(const pc_codec* c, size_t* total_bytes, int* n_strings);
-PC_API int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens);
+PC_API int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens, size_t lens_cap);
 PC_API int pc_codec_decompress_packed(pc_codec* c, const uint8_t* data, const size_t* lens, int B, int zh, int zw,
                                       const double* qualities, int n_levels, int mask_pol, float* x_hat, void* stream);
 
@@ -202,9 +222,11 @@ PC_API int pc_codec_decompress_packed(pc_codec* c, const uint8_t* data, const si
  * behind test_epoch / valid_epoch (training/step.py:215-267).  Runs the encoder chain without entropy coding and returns the
  * likelihood tensors: y_lik device [B][320 or 640][H/16][W/16] (640 when quality != 0), z_lik device [B][192][H/64][W/64],
  * x_hat device [B][3][H][W] (identical to decompress(compress(x))), masks_out as in pc_codec_compress (may be NULL).
+ * force_enhanced != 0 with quality == 0 (:1006,1022,1064): both hyper-priors and the enhancement chain run with all-zero masks
+ * (every enhancement symbol 0), y_lik has 640 channels and x_hat comes from the enhancement synthesis g_s[1].
  * Needs the entropy_bottleneck._matrix/_bias/_factor tensors in the state dict (PC_ERR_STATE otherwise). */
 PC_API int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol, float* x_hat,
-                            float* y_lik, float* z_lik, float* masks_out, void* stream);
+                            float* y_lik, float* z_lik, float* masks_out, int force_enhanced, void* stream);
 
 /* Measurement aid (bench.py roofline leg): while profiling is on, every launch of the MFMA convolution kernel made by
  * compress()/decompress() is bracketed by HIP events on the call's stream; _end returns the launch count, the summed

@@ -46,8 +46,9 @@ class CodecConfig:
         return self.division_dimension[1] // self.dim_chunk
 
     def check_supported(self):
-        """The native runtime implements exactly the canonical topology."""
-        ok = (self.multiple_decoder and not self.multiple_encoder and self.multiple_hyperprior
+        """The native runtime implements the canonical topology, with one encoder (WACNN's 3 -> M g_a, cnn.py:34-44) or with
+        multiple_encoder=True (two 3 -> 320 encoders whose outputs are concatenated, CHProg_cnn.py:131-144,691-697)."""
+        ok = (self.multiple_decoder and self.multiple_hyperprior
               and self.delta_encode and self.joiner_policy == "res"
               and self.support_progressive_slices == 5 and self.max_support_slices == 5
               and self.dim_chunk == 32 and tuple(self.division_dimension) == (320, 640)
@@ -129,13 +130,15 @@ def param_spec(cfg: CodecConfig = CodecConfig()) -> "OrderedDict[str, tuple]":
     cfg.check_supported()
     N, M, d0, H = cfg.N, cfg.M, cfg.division_dimension[0], cfg.num_heads
     s = OrderedDict()
-    # g_a (cnn.py:34-44): conv GDN conv GDN WAM(8,4) conv GDN conv(->M) WAM(4,2)
-    _conv(s, "g_a.0", 3, N, 5); _gdn(s, "g_a.1", N)
-    _conv(s, "g_a.2", N, N, 5); _gdn(s, "g_a.3", N)
-    _wam(s, "g_a.4", N, 8, H)
-    _conv(s, "g_a.5", N, N, 5); _gdn(s, "g_a.6", N)
-    _conv(s, "g_a.7", N, M, 5)
-    _wam(s, "g_a.8", M, 4, H)
+    # g_a (cnn.py:34-44): conv GDN conv GDN WAM(8,4) conv GDN conv(->M) WAM(4,2); multiple_encoder (CHProg_cnn.py:131-144): a
+    # ModuleList of two such nets ending in d0 = 320 channels each (keys g_a.<k>.<layer>...)
+    for p, cout in ((("g_a.0", d0), ("g_a.1", d0)) if cfg.multiple_encoder else (("g_a", M),)):
+        _conv(s, p + ".0", 3, N, 5); _gdn(s, p + ".1", N)
+        _conv(s, p + ".2", N, N, 5); _gdn(s, p + ".3", N)
+        _wam(s, p + ".4", N, 8, H)
+        _conv(s, p + ".5", N, N, 5); _gdn(s, p + ".6", N)
+        _conv(s, p + ".7", N, cout, 5)
+        _wam(s, p + ".8", cout, 4, H)
     # g_s[0..1] (CHProg_cnn.py:149-161)
     for k in range(2):
         p = f"g_s.{k}"

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <new>
 #include <cmath>
 #include <cstdio>
@@ -29,13 +30,16 @@
 #include "pc_device.h"
 #include "pc_host.h"
 
-static thread_local int g_last_hip = 0;
+// last HIP error seen by ANY thread of the library (the decoder's chains run on their own host threads: a thread-local would hide
+// their errors from the caller of pc_last_hip_error)
+static std::atomic<int> g_last_hip{0};
 struct pc_codec;
 static thread_local pc_codec* g_prof = nullptr;   // codec whose conv launches are being timed (profile mode)
+static thread_local pc_rowtab_cache* g_rowtabs = nullptr;   // row-table cache of the codec this thread is working for
 #define HIPCHK(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { g_last_hip = (int)_e; return PC_ERR_HIP; } } while (0)
 #define PCCHK(expr) do { int _r = (expr); if (_r != PC_OK) return _r; } while (0)
 
-extern "C" int pc_last_hip_error(void) { return g_last_hip; }
+extern "C" int pc_last_hip_error(void) { return g_last_hip.load(); }
 
 namespace {
 
@@ -65,11 +69,14 @@ struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 struct pc_codec {
     int device = 0;
     bool finalized = false;
+    pc_rowtab_cache* rowtabs = nullptr;          // per-geometry row tables of the conv kernel: owned here, freed in pc_codec_destroy
     std::map<std::string, HostTensor> sd;
     std::vector<void*> weight_allocs;
     std::map<std::string, DevBuf> bufs;          // grow-only named workspace
     // network
-    ConvW ga0, ga2, ga5, ga7; GdnW ga1, ga3, ga6; WamW ga4, ga8;
+    struct GaW { ConvW c0, c2, c5, c7; GdnW g1, g3, g6; WamW w4, w8; };
+    GaW ga[2];                                   // ga[1] only with multiple_encoder (CHProg_cnn.py:131-144)
+    bool multi_enc = false;                      // two 3 -> 320 encoders, y = cat(g_a[0](x), g_a[1](x))  (:691-697)
     GsW gs[2];
     ConvW ha[5];
     HsW hms[2], hss[2];
@@ -131,8 +138,10 @@ struct pc_codec {
 namespace {
 
 // conv launch, optionally bracketed by HIP events on the launch stream (profile mode)
-int launch_conv(const pc_conv_params& q, hipStream_t st)
+int launch_conv(const pc_conv_params& q_in, hipStream_t st)
 {
+    pc_conv_params q = q_in;
+    q.rowtab_cache = g_rowtabs;
     pc_codec* c = g_prof;
     if (!c) return pc_conv_launch(q, st);
     if (c->ev_used + 2 > c->ev.size()) {
@@ -399,9 +408,10 @@ int ru(hipStream_t st, const RuW& r, const float* x, int C, int B, int H, int W,
 }
 
 // Win_noShift_Attention (layers/layers.py:59-75)
-int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H, int W, float* out)
+int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H, int W, float* out, int ldo = 0)
 {
     const int C = w.C;
+    if (ldo == 0) ldo = C;                                              // output pixel stride (a channel slice of a wider tensor)
     const size_t M = (size_t)B * H * W;
     float *t1, *t2, *a0, *a1, *qkv, *o;
     PCCHK(c->buf("wam_t1", M * (C / 2), &t1));
@@ -423,7 +433,7 @@ int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H
     PCCHK(ru(st, w.b[0], o, C, B, H, W, t1, t2, b1));
     PCCHK(ru(st, w.b[1], b1, C, B, H, W, t1, t2, o));
     PCCHK(ru(st, w.b[2], o, C, B, H, W, t1, t2, b1));
-    PCCHK(conv(st, w.out, {{b1, C, C}}, B, H, W, 1, out, C, PC_EPI_GATE, a0, C, x, C));   // a * sigmoid(b) + x
+    PCCHK(conv(st, w.out, {{b1, C, C}}, B, H, W, 1, out, ldo, PC_EPI_GATE, a0, C, x, C));   // a * sigmoid(b) + x
     return PC_OK;
 }
 
@@ -484,8 +494,10 @@ int hs(pc_codec* c, hipStream_t st, const HsW& h, const float* z, int B, int zh,
     return PC_OK;
 }
 
-int g_a(pc_codec* c, hipStream_t st, const float* x, int B, int H, int W, float* y)
+// one analysis transform (models/cnn.py:34-44): x NCHW [B][3][H][W] -> out [B][H/16][W/16][Cy] written with pixel stride ldy
+int g_a_net(pc_codec* c, hipStream_t st, const pc_codec::GaW& g, const float* x, int B, int H, int W, float* y, int ldy)
 {
+    const int Cy = g.c7.Cout;
     float *t0, *t1, *t2, *t3, *t4;
     PCCHK(c->buf("ga_t0", (size_t)B * (H / 2) * (W / 2) * NCH, &t0));
     PCCHK(c->buf("ga_t1", (size_t)B * (H / 2) * (W / 2) * NCH, &t1));
@@ -499,20 +511,29 @@ int g_a(pc_codec* c, hipStream_t st, const float* x, int B, int H, int W, float*
         q.B = B; q.H = H; q.W = W;
         q.in_sb = (int64_t)3 * H * W; q.in_sc = (int64_t)H * W; q.in_sy = W; q.in_sx = 1;
         fill_conv_taps(q, 5, 2);
-        q.w = c->ga0.w; q.bias = c->ga0.b; q.Cout = NCH;
+        q.w = g.c0.w; q.bias = g.c0.b; q.Cout = NCH;
         q.Ho = H / 2; q.Wo = W / 2; q.outH = q.Ho; q.outW = q.Wo; q.M = B * q.Ho * q.Wo;
         q.out = t0; q.out_sc = 1; q.out_sx = NCH; q.out_sy = (int64_t)q.Wo * NCH; q.out_sb = (int64_t)q.Ho * q.Wo * NCH;
         PCCHK(launch_conv(q, st));
     }
-    PCCHK(gdn(st, c->ga1, t0, B, H / 2, W / 2, false, t1));
-    PCCHK(conv(st, c->ga2, {{t1, NCH, NCH}}, B, H / 2, W / 2, 2, t2, NCH, PC_EPI_NONE));
-    PCCHK(gdn(st, c->ga3, t2, B, H / 4, W / 4, false, t3));
-    PCCHK(wam(c, st, c->ga4, t3, B, H / 4, W / 4, t2));
-    PCCHK(conv(st, c->ga5, {{t2, NCH, NCH}}, B, H / 4, W / 4, 2, t0, NCH, PC_EPI_NONE));
-    PCCHK(gdn(st, c->ga6, t0, B, H / 8, W / 8, false, t1));
-    PCCHK(conv(st, c->ga7, {{t1, NCH, NCH}}, B, H / 8, W / 8, 2, t4, MLAT, PC_EPI_NONE));
-    PCCHK(wam(c, st, c->ga8, t4, B, H / 16, W / 16, y));
+    PCCHK(gdn(st, g.g1, t0, B, H / 2, W / 2, false, t1));
+    PCCHK(conv(st, g.c2, {{t1, NCH, NCH}}, B, H / 2, W / 2, 2, t2, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, g.g3, t2, B, H / 4, W / 4, false, t3));
+    PCCHK(wam(c, st, g.w4, t3, B, H / 4, W / 4, t2));
+    PCCHK(conv(st, g.c5, {{t2, NCH, NCH}}, B, H / 4, W / 4, 2, t0, NCH, PC_EPI_NONE));
+    PCCHK(gdn(st, g.g6, t0, B, H / 8, W / 8, false, t1));
+    PCCHK(conv(st, g.c7, {{t1, NCH, NCH}}, B, H / 8, W / 8, 2, t4, Cy, PC_EPI_NONE));
+    PCCHK(wam(c, st, g.w8, t4, B, H / 16, W / 16, y, ldy));
     return PC_OK;
+}
+
+// y = g_a(x), or cat(g_a[0](x), g_a[1](x)) over channels with multiple_encoder (CHProg_cnn.py:691-697): the second net writes
+// channels 320.. of the same [M][640] buffer -- a virtual concatenation, no copy
+int g_a(pc_codec* c, hipStream_t st, const float* x, int B, int H, int W, float* y)
+{
+    if (!c->multi_enc) return g_a_net(c, st, c->ga[0], x, B, H, W, y, MLAT);
+    PCCHK(g_a_net(c, st, c->ga[0], x, B, H, W, y, MLAT));
+    return g_a_net(c, st, c->ga[1], x, B, H, W, y + D0, MLAT);
 }
 
 // g_s[k] (CHProg_cnn.py:149-161): y_hat [B][h][w][320] -> x_hat NCHW [B][3][16h][16w], clamped to [0,1]
@@ -767,6 +788,8 @@ extern "C" int pc_codec_create(pc_codec** out, int device)
     pc_codec* c = new (std::nothrow) pc_codec;
     if (!c) return PC_ERR_NOMEM;
     c->device = device;
+    c->rowtabs = pc_rowtab_cache_create((size_t)512 << 20);          // <= 512 MB of row tables per codec, least recently used evicted
+    if (!c->rowtabs) { delete c; return PC_ERR_NOMEM; }
     *out = c;
     return PC_OK;
 }
@@ -775,6 +798,8 @@ extern "C" void pc_codec_destroy(pc_codec* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();                                    // nothing of this codec is in flight when its memory goes
+    pc_rowtab_cache_destroy(c->rowtabs);
     for (void* p : c->weight_allocs) (void)hipFree(p);
     for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
@@ -830,15 +855,21 @@ extern "C" int pc_codec_finalize(pc_codec* c)
     if (!c) return PC_ERR_ARG;
     if (c->finalized) return PC_OK;
     HIPCHK(hipSetDevice(c->device));
-    PCCHK(load_conv(c, "g_a.0", 3, NCH, 5, 0, &c->ga0));
-    PCCHK(load_gdn(c, "g_a.1", NCH, &c->ga1));
-    PCCHK(load_conv(c, "g_a.2", NCH, NCH, 5, 0, &c->ga2));
-    PCCHK(load_gdn(c, "g_a.3", NCH, &c->ga3));
-    PCCHK(load_wam(c, "g_a.4", NCH, 8, 4, &c->ga4));
-    PCCHK(load_conv(c, "g_a.5", NCH, NCH, 5, 0, &c->ga5));
-    PCCHK(load_gdn(c, "g_a.6", NCH, &c->ga6));
-    PCCHK(load_conv(c, "g_a.7", NCH, MLAT, 5, 0, &c->ga7));
-    PCCHK(load_wam(c, "g_a.8", MLAT, 4, 2, &c->ga8));
+    c->multi_enc = c->sd.count("g_a.0.0.weight") != 0;                  // ModuleList of two encoders: keys g_a.<k>.<layer>...
+    for (int k = 0; k < (c->multi_enc ? 2 : 1); ++k) {
+        const std::string p = c->multi_enc ? "g_a." + std::to_string(k) : std::string("g_a");
+        const int Cy = c->multi_enc ? D0 : MLAT;
+        pc_codec::GaW& g = c->ga[k];
+        PCCHK(load_conv(c, p + ".0", 3, NCH, 5, 0, &g.c0));
+        PCCHK(load_gdn(c, p + ".1", NCH, &g.g1));
+        PCCHK(load_conv(c, p + ".2", NCH, NCH, 5, 0, &g.c2));
+        PCCHK(load_gdn(c, p + ".3", NCH, &g.g3));
+        PCCHK(load_wam(c, p + ".4", NCH, 8, 4, &g.w4));
+        PCCHK(load_conv(c, p + ".5", NCH, NCH, 5, 0, &g.c5));
+        PCCHK(load_gdn(c, p + ".6", NCH, &g.g6));
+        PCCHK(load_conv(c, p + ".7", NCH, Cy, 5, 0, &g.c7));
+        PCCHK(load_wam(c, p + ".8", Cy, 4, 2, &g.w8));
+    }
     for (int k = 0; k < 2; ++k) {
         const std::string p = "g_s." + std::to_string(k);
         GsW& g = c->gs[k];
@@ -911,6 +942,22 @@ extern "C" int pc_codec_finalize(pc_codec* c)
     return PC_OK;
 }
 
+extern "C" int pc_codec_set_scale_table(pc_codec* c, const float* table, int n)
+{
+    // GaussianConditional.update_scale_table (entropy_models.py:588-597): a new table of scales for build_indexes; the caller sets the
+    // matching CDF tables with pc_codec_set_tables
+    if (!c || !table || n < 2 || n > 64) return PC_ERR_ARG;
+    if (!c->finalized) return PC_ERR_STATE;
+    for (int i = 0; i + 1 < n; ++i) if (!(table[i] < table[i + 1])) return PC_ERR_ARG;     // the index search needs an ascending table
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> t(table, table + n);
+    float* dev = nullptr;
+    PCCHK(upload(c, t, &dev));
+    c->scale_table = dev; c->n_table = n;
+    return PC_OK;
+}
+
 extern "C" int pc_codec_set_cust_map(pc_codec* c, const float* cust_map)
 {
     if (!c) return PC_ERR_ARG;
@@ -944,6 +991,17 @@ namespace {
 #define PC_DEFAULT_LANES_ENC 1
 #define PC_DEFAULT_LANES_DEC 2
 
+// hand-off between the two pipelined chains' host threads: slice i's event has been recorded (or the producer failed)
+struct SliceSignal {
+    std::mutex m;
+    std::condition_variable cv;
+    int count = 0;
+    bool failed = false;
+    void publish(int n) { { std::lock_guard<std::mutex> lk(m); count = n; } cv.notify_all(); }
+    void fail() { { std::lock_guard<std::mutex> lk(m); failed = true; } cv.notify_all(); }
+    bool wait_for(int i) { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return failed || count > i; }); return !failed; }   // false: producer failed
+};
+
 struct ChainCtx {
     pc_codec* c;
     int B, h, w, HW;
@@ -956,9 +1014,9 @@ struct ChainCtx {
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
     const float* cust_map;                      // NCHW [B][320][HW]: enhancement masks threshold this map instead of the scale
     hipEvent_t* sig;                            // if set: record sig[i] on the lane's stream once slice i (of this pass) is complete
-    std::atomic<int>* sig_count;                //         ... and publish the number of recorded events to other host threads
+    SliceSignal* sig_count;                     //         ... and publish the number of recorded events to other host threads
     hipEvent_t* waitv;                          // if set: slice i of this pass starts only after waitv[i] (recorded by the other chain)
-    std::atomic<int>* wait_count;               //         host side: do not look at waitv[i] before it has been recorded
+    SliceSignal* wait_count;                    //         host side: do not look at waitv[i] before it has been recorded
     size_t h_off;                               // decoder: offset (int32 units) of this chain's region in the pinned staging buffers
     int32_t *so_sym, *so_idx;                   // streamed pass (single lane): pinned destinations; slice i of the pass is copied to
                                                 // so_sym + i*M*SLICE on c->copy_stream as soon as its prep kernel is done
@@ -1069,10 +1127,7 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     for (int step = k.step0; step < k.step1; ++step) {
         if (k.waitv) {                                                                   // pipelined against the other chain
             const int i = step >= NS0 ? step - NS0 : step;
-            if (k.wait_count) {
-                while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
-                if (k.wait_count->load(std::memory_order_acquire) >= (1 << 20)) return PC_ERR_STATE;    // the other chain failed
-            }
+            if (k.wait_count && !k.wait_count->wait_for(i)) return PC_ERR_STATE;             // the other chain failed
             HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
         }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
@@ -1106,7 +1161,7 @@ int encode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         if (k.sig) {
             const int i = step >= NS0 ? step - NS0 : step;
             HIPCHK(hipEventRecord(k.sig[i], sA));
-            if (k.sig_count) k.sig_count->store(i + 1, std::memory_order_release);
+            if (k.sig_count) k.sig_count->publish(i + 1);
         }
     }
     return PC_OK;
@@ -1117,16 +1172,14 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
 {
     pc_codec* c = k.c;
     HIPCHK(hipSetDevice(c->device));
+    g_rowtabs = c->rowtabs;                                                             // (this may be a lane's own host thread)
     const size_t pi = (size_t)k.HW, per = (size_t)SLICE * k.HW;
     int32_t* h_idx = c->h_idx + k.h_off + (size_t)b0 * per;
     int32_t* h_sym = c->h_sym + k.h_off + (size_t)b0 * per;
     for (int step = k.step0; step < k.step1; ++step) {
         if (k.waitv) {                                                                   // pipelined against the other chain
             const int i = step >= NS0 ? step - NS0 : step;
-            if (k.wait_count) {
-                while (k.wait_count->load(std::memory_order_acquire) <= i) std::this_thread::yield();
-                if (k.wait_count->load(std::memory_order_acquire) >= (1 << 20)) return PC_ERR_STATE;    // the other chain failed
-            }
+            if (k.wait_count && !k.wait_count->wait_for(i)) return PC_ERR_STATE;             // the other chain failed
             HIPCHK(hipStreamWaitEvent(sA, k.waitv[i], 0));
         }
         PCCHK(chain_params(k, step, b0, nb, sA, sB, eA, eB, tag));
@@ -1151,7 +1204,7 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         if (k.sig) {
             const int i = step >= NS0 ? step - NS0 : step;
             HIPCHK(hipEventRecord(k.sig[i], sA));
-            if (k.sig_count) k.sig_count->store(i + 1, std::memory_order_release);
+            if (k.sig_count) k.sig_count->publish(i + 1);
         }
     }
     return PC_OK;
@@ -1181,12 +1234,12 @@ int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* con
         }
     }
     HIPCHK(hipEventRecord(c->eFork, st));
+    for (int g = 0; g < nl; ++g) HIPCHK(hipStreamWaitEvent(c->lanes[g].sA, c->eFork, 0));     // every fallible fork step BEFORE a thread exists
     std::vector<int> rcs(nl, PC_OK);
     std::vector<std::thread> threads;
     for (int g = 0; g < nl; ++g) {
         const int b0 = (int)((long)k.B * g / nl), nb = (int)((long)k.B * (g + 1) / nl) - b0;
         pc_codec::Lane& L = c->lanes[g];
-        HIPCHK(hipStreamWaitEvent(L.sA, c->eFork, 0));
         const std::string tag = std::to_string(g);
         if (decode) {
             threads.emplace_back([&, g, b0, nb, tag] {
@@ -1197,14 +1250,16 @@ int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* con
             rcs[g] = encode_lane(k, b0, nb, L.sA, L.sB, L.eA, L.eB, tag);
         }
     }
-    for (auto& t : threads) t.join();
-    for (int g = 0; g < nl; ++g) {
+    for (auto& t : threads) t.join();                                                          // nothing between creation and join can return
+    int rc = PC_OK;
+    for (int g = 0; g < nl; ++g) {                                                             // join every lane, remember the first error
         pc_codec::Lane& L = c->lanes[g];
-        HIPCHK(hipEventRecord(L.eDone, L.sA));
-        HIPCHK(hipStreamWaitEvent(st, L.eDone, 0));
+        hipError_t e = hipEventRecord(L.eDone, L.sA);
+        if (e == hipSuccess) e = hipStreamWaitEvent(st, L.eDone, 0);
+        if (e != hipSuccess && rc == PC_OK) { g_last_hip = (int)e; rc = PC_ERR_HIP; }
     }
     for (int g = 0; g < nl; ++g) if (rcs[g] != PC_OK) return rcs[g];
-    return PC_OK;
+    return rc;
 }
 
 }  // namespace
@@ -1279,6 +1334,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     if (c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     g_prof = c->profile ? c : nullptr;
+    g_rowtabs = c->rowtabs;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
     bool any_enh = false;
@@ -1456,7 +1512,10 @@ extern "C" int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int 
 {
     float* const m[1] = {masks_out};
     const int r = compress_impl(c, x, B, H, W, &quality, 1, mask_pol, masks_out ? m : nullptr, (hipStream_t)stream);
-    if (r == PC_OK && quality <= 0) c->res_slices = NS0;        // compress() at quality 0 returns the ten base slices only
+    if (r == PC_OK && quality <= 0) {                           // compress() at quality 0 returns the ten base slices only (:766-767):
+        c->res_slices = NS0;                                    // pc_codec_num_slices, _strings_size and _copy_strings all say 10*B + B
+        c->y_strings.resize((size_t)NS0 * B);
+    }
     return r;
 }
 
@@ -1478,13 +1537,14 @@ extern "C" int pc_codec_strings_size(const pc_codec* c, size_t* total_bytes, int
     return PC_OK;
 }
 
-extern "C" int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens)
+extern "C" int pc_codec_copy_strings(const pc_codec* c, uint8_t* dst, size_t cap, size_t* lens, size_t lens_cap)
 {
     if (!c || !dst || !lens) return PC_ERR_ARG;
+    if (lens_cap < c->y_strings.size() + c->z_strings.size()) return PC_ERR_BUFFER;
     size_t off = 0, k = 0;
     for (const std::vector<std::vector<uint8_t>>* v : {&c->y_strings, &c->z_strings})
         for (const auto& s : *v) {
-            if (off + s.size() > cap) return PC_ERR_ARG;
+            if (off + s.size() > cap) return PC_ERR_BUFFER;
             if (!s.empty()) std::memcpy(dst + off, s.data(), s.size());
             off += s.size(); lens[k++] = s.size();
         }
@@ -1509,7 +1569,7 @@ extern "C" int pc_codec_get_level_string(const pc_codec* c, int level, int slice
 // fused mask / index / quantise kernel, the hyper-latent's from the EntropyBottleneck density network (:400-433) -- followed by the
 // synthesis transform.  x_hat equals decompress(compress(x)) bit for bit (same y_hat); estimated bits = -sum(log2(likelihood)).
 extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W, double quality, int mask_pol, float* x_hat,
-                                float* y_lik, float* z_lik, float* masks_out, void* stream)
+                                float* y_lik, float* z_lik, float* masks_out, int force_enhanced, void* stream)
 {
     if (!c || !x || !x_hat || !y_lik || !z_lik || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
     if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
@@ -1517,9 +1577,10 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     g_prof = c->profile ? c : nullptr;
+    g_rowtabs = c->rowtabs;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
-    const bool enh = quality != 0;                                                       // :1063 "if quality == 0 and force_enhanced is False"
+    const bool enh = quality != 0 || force_enhanced != 0;                                // :1063 "if quality == 0 and force_enhanced is False"
     c->last_B = B; c->last_h16 = h; c->last_w16 = w;
 
     ChainCtx k;
@@ -1591,6 +1652,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     g_prof = c->profile ? c : nullptr;
+    g_rowtabs = c->rowtabs;
     const int h = 4 * zh, w = 4 * zw, HW = h * w, ZHW = zh * zw;
     const size_t M = (size_t)B * HW;
     bool any_enh = false;
@@ -1638,7 +1700,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         PCCHK(ensure_host_staging(c, std::max(2 * per * B, per_z * B)));
         HIPCHK(hipEventRecord(c->pipe_ev[NS0], st));
         HIPCHK(hipStreamWaitEvent(c->pipe_stream, c->pipe_ev[NS0], 0));
-        std::atomic<int> recorded{0};
+        SliceSignal recorded;
         ChainCtx kb = k, ke = k;
         kb.step0 = 0; kb.step1 = NS0; kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data(); kb.sig_count = &recorded; kb.h_off = 0;
         ke.step0 = NS0; ke.step1 = 2 * NS0; ke.enh = true; ke.level = first_enh; ke.waitv = c->pipe_ev.data(); ke.wait_count = &recorded;
@@ -1647,14 +1709,17 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         int rb = PC_OK;
         std::thread tb([&] {
             rb = decode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt);                  // :874-904
-            if (rb != PC_OK) recorded.store(1 << 20, std::memory_order_release);                               // release the other chain
+            if (rb != PC_OK) recorded.fail();                                                                  // release the other chain
         });
         const int re = decode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB", y_strings, y_lens, nt);   // :930-983
         tb.join();
+        // join pipe_stream back into `st` whatever happened: a failed call must not leave work of its own running beside the next one
+        const hipError_t ej = hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream);
+        const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0) : ej;
+        if (rb != PC_OK || re != PC_OK) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamSynchronize(st); }
         if (rb != PC_OK) return rb;
         if (re != PC_OK) return re;
-        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
-        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+        HIPCHK(ew);
     } else {
         k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
         PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :874-904

@@ -33,7 +33,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include <type_traits>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/pc_math.h"
@@ -546,6 +548,13 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
     }
 
     // ---------------------------------------------------------------------- MFMA waves
+    if (p.dbg & 512) {                                     // experiment: distinct issue priorities for the workgroups sharing a CU
+        switch ((blockIdx.x >> 8) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(2); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    }
     const int wm = wave / WN, wn = wave % WN;
     const int half = lane >> 5, l31 = lane & 31;
     const int am = wm * 32 + l31, bn = wn * 32 + l31;      // this lane's A row / B row inside the block tile
@@ -678,7 +687,8 @@ __global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_
 //            s_barrier                   everyone's have; everyone is done reading chunk c-1
 //            MFMAs of chunk c, with the NI pieces of chunk c+S-1 (into the stage chunk c-1 occupied) between them
 // ------------------------------------------------------------------------------------------
-template <int BK, int S, int TM, int TN, bool SQ>
+// DBG (tuning builds only, PC_CONV_DBG): 1 no MFMAs, 2 no DMA issue, 4 every DMA piece out of range (zero fill, no L2 traffic), 8 no operand reads
+template <int BK, int S, int TM, int TN, bool SQ, int DBG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_params p)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN, KQ = BK / 4;
@@ -693,6 +703,19 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     extern __shared__ float4 smem[];                        // S stages, then the run table (launch_uni sizes it)
 
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    if (p.dbg & 512) {
+        // Workgroups that share a CU were dispatched ~256 ids apart (round-robin over the CUs): give them different issue priorities so
+        // that one of them runs at full rate and the others fill its stalls, instead of all advancing in lockstep and meeting at
+        // their barriers together.  Speed only; nothing depends on the placement guess.
+        switch ((blockIdx.x >> 8) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(3); break;
+        case 1: __builtin_amdgcn_s_setprio(2); break;
+        case 2: __builtin_amdgcn_s_setprio(1); break;
+        default: __builtin_amdgcn_s_setprio(0); break;
+        }
+    }
+    unsigned long long tl[4] = {0, 0, 0, 0};               // DBG & 64: timeline of this wave in s_memrealtime ticks (100 MHz, chip-wide)
+    if (DBG & 64) tl[0] = __builtin_amdgcn_s_memrealtime();
     // XCD-aware tile order: see conv_igemm_dma_kernel
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     const int mpx = (MT + 7) >> 3;
@@ -819,11 +842,12 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     auto prepare = [&]() {
         const bool full = c_left >= BK;
 #pragma unroll
-        for (int i = 0; i < AIN; ++i) ea[i] = (full || 4 * a_q[i] < c_left) ? a_off[i] : OOB;
+        for (int i = 0; i < AIN; ++i) ea[i] = ((full || 4 * a_q[i] < c_left) && !(DBG & 4)) ? a_off[i] : OOB;
 #pragma unroll
-        for (int i = 0; i < BIN; ++i) eb[i] = (full || 4 * b_q[i] < c_left) ? b_off[i] : OOB;
+        for (int i = 0; i < BIN; ++i) eb[i] = ((full || 4 * b_q[i] < c_left) && !(DBG & 4)) ? b_off[i] : OOB;
     };
     auto piece = [&](int q, int stage, const __amdgpu_buffer_rsrc_t& rsrc_a, const __amdgpu_buffer_rsrc_t& rsrc_b) {
+        if (DBG & 2) return;
         float4* base = smem + stage * STAGE;
         if (q < AIN)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(base + (wave * AIN + q) * 64), 16, ea[q < AIN ? q : 0], koff, 0, 0);
@@ -879,9 +903,23 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             }
             return;
         }
+        if (ISSUE && (DBG & 16)) {
+#pragma unroll
+            for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
+        }
         const uint32_t st_off = (uint32_t)st_c * (uint32_t)(STAGE * 16);
         f32x4 va[2][TM], vb[2][TN];
+        if (DBG & 8) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) va[h2][i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) vb[h2][j] = f32x4{1.f, 2.f, 3.f, 4.f};
+            }
+        }
         auto reads = [&](int g) {
+            if (DBG & 8) return;
             const uint32_t aa = a_addr[g] + st_off, ba = b_addr[g] + st_off;
 #pragma unroll
             for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va[g & 1][i]) : "v"(aa), "n"(i * 32 * KQ * 16));
@@ -896,6 +934,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             // the wait so that no MFMA using them can be scheduled above it
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
+                if (DBG & 8) continue;
                 if (g + 1 < NG) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(va[g & 1][i]) : "n"(TM + NL));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[g & 1][i]));
             }
@@ -917,8 +956,8 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i][s], xb[j][s], acc[i][j], 0, 0, 0);
-                        if (ISSUE) {
+                        if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i][s], xb[j][s], acc[i][j], 0, 0, 0);
+                        if (ISSUE && !(DBG & 16)) {
                             const int slot_ix = ((g * 4 + s) * TM + i) * NL + j;      // compile-time after unrolling
 #pragma unroll
                             for (int q = 0; q < NI; ++q)
@@ -958,13 +997,24 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             st_c = st_c + 1 == S ? 0 : st_c + 1;
         }
     };
+    if (DBG & 64) tl[1] = __builtin_amdgcn_s_memrealtime();
     if (nlive == TN) kloop(std::integral_constant<int, TN>{});
     else if (nlive == 0) kloop(std::integral_constant<int, 0>{});
     else kloop(std::integral_constant<int, 1>{});                     // TN == 2 only
+    if (DBG & 64) tl[2] = __builtin_amdgcn_s_memrealtime();
     __builtin_amdgcn_s_barrier();                                     // every wave is done with the stages: the epilogue reuses them
+    auto stamp_out = [&]() {
+        if (!(DBG & 64) || lane != 0 || blockIdx.x >= 8192 / 4) return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long* d = pc_dbg_stamps[blockIdx.x * 4 + wave];
+        d[0] = tl[0]; d[1] = tl[1]; d[2] = tl[2]; d[3] = __builtin_amdgcn_s_memrealtime();
+        d[4] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF804);      // HW_REG_HW_ID
+        d[5] = (unsigned long long)__builtin_amdgcn_s_getreg(0xF814);      // HW_REG_XCC_ID
+        d[6] = (unsigned long long)nlive; d[7] = (unsigned long long)blockIdx.x;
+    };
 
     // ---- epilogue, tile by tile
-    if (nlive == 0) return;
+    if (nlive == 0) { stamp_out(); return; }
     const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
     float* tile = reinterpret_cast<float*>(smem + wave * 512);        // 2 x 4 KB per wave (S * STAGE >= 2048 float4)
 #pragma unroll
@@ -1024,6 +1074,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                 }
             }
         }
+    stamp_out();
 #endif
 }
 
@@ -1052,14 +1103,72 @@ struct RowTabKey {
     int dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
     bool operator==(const RowTabKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
 };
-struct RowTabEntry { RowTabKey key; int* tab; };
 
-// returns the cached table for this layer geometry, building it on first use (synchronously: other streams may use it right away)
+}  // namespace
+
+// Cache of the per-geometry row tables.  One per codec object (pc_codec owns it and frees it in pc_codec_destroy) plus one
+// process-wide instance for the stand-alone entry points (pc_conv2d_nhwc ...).  Hash lookup, LRU order, a byte cap: a service that
+// sees thousands of distinct image sizes keeps a bounded amount of HBM.  A table is built asynchronously on the stream
+// that first needs it; other streams order themselves behind its `ready` event -- no host synchronisation on the launch path.
+struct pc_rowtab_cache {
+    struct Entry { RowTabKey key; int* tab; size_t bytes; hipEvent_t ready; bool done; uint64_t tick; };
+    std::mutex mu;
+    std::unordered_multimap<uint64_t, Entry> map;
+    size_t bytes = 0, cap;
+    uint64_t tick = 0;
+    explicit pc_rowtab_cache(size_t cap_bytes) : cap(cap_bytes) {}
+    static uint64_t hash(const RowTabKey& k)
+    {
+        uint64_t h = 1469598103934665603ull;
+        const unsigned char* p = reinterpret_cast<const unsigned char*>(&k);
+        for (size_t i = 0; i < sizeof(k); ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        return h;
+    }
+    void release_all()
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : map) { (void)hipFree(kv.second.tab); (void)hipEventDestroy(kv.second.ready); }
+        map.clear();
+        bytes = 0;
+    }
+    // evict least-recently-used tables until `need` more bytes fit; the device is drained first (a launch in flight may still read them)
+    void make_room(size_t need)
+    {
+        if (bytes + need <= cap || map.empty()) return;
+        (void)hipDeviceSynchronize();
+        while (bytes + need > cap && !map.empty()) {
+            auto victim = map.begin();
+            for (auto it = map.begin(); it != map.end(); ++it) if (it->second.tick < victim->second.tick) victim = it;
+            (void)hipFree(victim->second.tab);
+            (void)hipEventDestroy(victim->second.ready);
+            bytes -= victim->second.bytes;
+            map.erase(victim);
+        }
+    }
+};
+
+pc_rowtab_cache* pc_rowtab_cache_create(size_t cap_bytes) { return new (std::nothrow) pc_rowtab_cache(cap_bytes); }
+void pc_rowtab_cache_destroy(pc_rowtab_cache* c)
+{
+    if (!c) return;
+    c->release_all();
+    delete c;
+}
+size_t pc_rowtab_cache_bytes(pc_rowtab_cache* c) { if (!c) return 0; std::lock_guard<std::mutex> lk(c->mu); return c->bytes; }
+
+namespace {
+
+pc_rowtab_cache* default_rowtab_cache()
+{
+    static pc_rowtab_cache cache((size_t)64 << 20);       // stand-alone entry points: at most 64 MB of tables per process
+    return &cache;
+}
+
+// the cached table for this layer geometry, built on first use on `stream`; nullptr = fall back to in-kernel row arithmetic
 const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
 {
-    static std::mutex mu;
-    static std::vector<RowTabEntry> cache;
     if ((int64_t)p.B * p.H * p.W >= (int64_t)1 << 31) return nullptr;          // pixel indices are int32 in the table
+    pc_rowtab_cache* rc = p.rowtab_cache ? reinterpret_cast<pc_rowtab_cache*>(p.rowtab_cache) : default_rowtab_cache();
     RowTabKey k;
     std::memset(&k, 0, sizeof(k));
     (void)hipGetDevice(&k.dev);
@@ -1068,14 +1177,31 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
         k.ntap[ph] = p.ntap[ph];
         for (int t = 0; t < p.ntap[ph]; ++t) { k.dy[ph][t] = p.dy[ph][t]; k.dx[ph][t] = p.dx[ph][t]; }
     }
-    std::lock_guard<std::mutex> lk(mu);
-    for (const RowTabEntry& e : cache) if (e.key == k) return e.tab;
-    int* tab = nullptr;
-    if (hipMalloc(reinterpret_cast<void**>(&tab), (size_t)(1 + p.nphase) * p.M * sizeof(int)) != hipSuccess) return nullptr;
-    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, tab);
-    if (hipStreamSynchronize(stream) != hipSuccess) { (void)hipFree(tab); return nullptr; }
-    cache.push_back(RowTabEntry{k, tab});
-    return tab;
+    const uint64_t h = pc_rowtab_cache::hash(k);
+    std::lock_guard<std::mutex> lk(rc->mu);
+    auto range = rc->map.equal_range(h);
+    for (auto it = range.first; it != range.second; ++it) {
+        pc_rowtab_cache::Entry& e = it->second;
+        if (!(e.key == k)) continue;
+        e.tick = ++rc->tick;
+        if (!e.done) {                                     // built on another stream a moment ago: order this stream behind it
+            if (hipEventQuery(e.ready) == hipSuccess) e.done = true;
+            else if (hipStreamWaitEvent(stream, e.ready, 0) != hipSuccess) return nullptr;
+        }
+        return e.tab;
+    }
+    const size_t bytes = (size_t)(1 + p.nphase) * p.M * sizeof(int);
+    if (bytes > rc->cap) return nullptr;
+    rc->make_room(bytes);
+    pc_rowtab_cache::Entry e;
+    e.key = k; e.bytes = bytes; e.done = false; e.tick = ++rc->tick; e.tab = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&e.tab), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) { (void)hipFree(e.tab); return nullptr; }
+    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, e.tab);
+    if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
+    rc->bytes += bytes;
+    rc->map.emplace(h, e);
+    return e.tab;
 }
 
 template <int BK, int S, int WM, int WN, bool SQ = false>
@@ -1108,7 +1234,7 @@ hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <int BK, int S, int TM, int TN, bool SQ = false>
+template <int BK, int S, int TM, int TN, bool SQ = false, int DBG = 0>
 hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN;
@@ -1117,7 +1243,7 @@ hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
     const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);
-    auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ>;
+    auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ, DBG>;
     static std::atomic<uint32_t> attr_set{0};             // bit per device: more than 64 KB of dynamic LDS allowed for this instantiation
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -1159,20 +1285,21 @@ int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
 }
 
 // Host-side validation + tile selection.  Returns a pc status code.
-int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
+int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
 {
+    pc_conv_params p = p_in;                               // derived fields (row table, fast-path flags, debug bits) are set on a private copy
     if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
     static const int dbg_env = [] { const char* v = std::getenv("PC_CONV_DBG"); return v ? std::atoi(v) : 0; }();
-    if (dbg_env) const_cast<pc_conv_params&>(p).dbg = dbg_env;
+    if (dbg_env) p.dbg = dbg_env;
     {   // row tables only pay for layers with several taps (1x1 layers: one tap, always valid)
         int tmax = 0;
         for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
         static const bool no_tab = [] { const char* v = std::getenv("PC_CONV_NO_ROWTAB"); return v && std::atoi(v) != 0; }();
-        const_cast<pc_conv_params&>(p).rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
+        p.rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
     }
-    const_cast<pc_conv_params&>(p).ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
+    p.ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
                                                 p.Ho == p.H && p.Wo == p.W;
-    const_cast<pc_conv_params&>(p).dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&
+    p.dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&
                                                p.outW == p.Wo && !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx &&
                                                p.out_sb == (int64_t)p.outH * p.out_sy;
     if (!p.smallc) {
@@ -1220,10 +1347,20 @@ int pc_conv_launch(const pc_conv_params& p, hipStream_t stream)
         if (kern_env == 1) {
             int tm = tm_env ? tm_env : 1, tn = tn_env ? tn_env : 1;
             const int Su = s_env ? s_env : (chunks <= 8 ? 2 : 3);
+            const int ab = (p.dbg & 64) ? 0 : (p.dbg & 15);                   // ablation builds of the 64x64 three-stage instantiation
             if (p.square) e = launch_uni<32, 2, 1, 1, true>(p, stream);
+            else if (ab == 1) e = launch_uni<32, 3, 1, 1, false, 1>(p, stream);
+            else if (ab == 2) e = launch_uni<32, 3, 1, 1, false, 2>(p, stream);
+            else if (ab == 4) e = launch_uni<32, 3, 1, 1, false, 4>(p, stream);
+            else if (ab == 8) e = launch_uni<32, 3, 1, 1, false, 8>(p, stream);
+            else if (ab == 10) e = launch_uni<32, 3, 1, 1, false, 10>(p, stream);
+            else if (ab == 3) e = launch_uni<32, 3, 1, 1, false, 3>(p, stream);
+            else if (ab == 0 && (p.dbg & 16) && !(p.dbg & 64)) e = launch_uni<32, 3, 1, 1, false, 16>(p, stream);
+            else if ((p.dbg & 64) && (p.dbg & 8)) e = launch_uni<32, 3, 1, 1, false, 74>(p, stream);
+            else if (p.dbg & 64) e = launch_uni<32, 3, 1, 1, false, 64>(p, stream);
 #define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
             PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
-            PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2)
+            PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2) PC_UNI_CASE(4, 1, 1)
 #undef PC_UNI_CASE
         }
         else if (p.square) e = launch_dma<32, 2, 2, 2, true>(p, stream);        // GDN / IGDN: K = C <= 320

@@ -68,12 +68,18 @@ struct pc_conv_params {
     const float* g1_seg0; const float* g1_w; const float* g1_bias; float* g1_out;
     const int* rowtab;                       // set by pc_conv_launch (layers with more than one tap): cached per layer geometry,
                                              // [M] input-pixel index of each GEMM row, then [nphase][M] tap-validity masks
+    void* rowtab_cache;                      // pc_rowtab_cache* of the calling codec (null: the process-wide cache of the stand-alone entry points)
     int ident_rows;                          // set by pc_conv_launch: 1x1 stride-1 layer, GEMM row m reads input pixel m (no row table)
     int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
     int dbg;                                 // tuning only (PC_CONV_DBG bits): 1 skip MFMAs, 2 skip DMA issue, 4 DMAs read the zero page, 64 stamps, 256 print occupancy
 };
 
 int pc_conv_launch(const pc_conv_params& p, hipStream_t stream);
+// row-table cache (pc_conv.hip): owned by a codec, freed with it; cap_bytes bounds the HBM it may hold (LRU eviction)
+struct pc_rowtab_cache;
+pc_rowtab_cache* pc_rowtab_cache_create(size_t cap_bytes);
+void pc_rowtab_cache_destroy(pc_rowtab_cache* c);
+size_t pc_rowtab_cache_bytes(pc_rowtab_cache* c);
 // weight layout the launcher expects for a layer (kind 0 conv / 1 transposed conv k5 s2)
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k);
 

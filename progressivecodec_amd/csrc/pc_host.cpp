@@ -5,8 +5,13 @@
 // third_party/ryg_rans/rans64.h) but is organised differently: symbols are walked backwards and
 // encoded straight into the output words (no intermediate record vector), and the decoder finds
 // the symbol by binary search over the CDF row instead of a linear scan.
+#include <pthread.h>
+#include <sched.h>
+
+#include <algorithm>
 #include <atomic>
 #include <cmath>
+#include <cstdio>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -102,18 +107,13 @@ extern "C" int pc_rans_encode_with_indexes(const int32_t* symbols, const int32_t
     return PC_OK;
 }
 
-extern "C" int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encoded_len,
-                                           const int32_t* indexes, size_t n,
-                                           const int32_t* cdfs, int n_cdf, int cdf_stride,
-                                           const int32_t* cdf_sizes, const int32_t* offsets,
-                                           int32_t* out)
+namespace {
+// decoder core: state (x, p = next word to read) lives with the caller so that a stream can be decoded in several calls
+int rans_decode_core(const uint8_t* encoded, size_t encoded_len, uint64_t& x, size_t& p, const int32_t* indexes, size_t n,
+                     const int32_t* cdfs, int n_cdf, int cdf_stride, const int32_t* cdf_sizes, const int32_t* offsets, int32_t* out)
 {
-    if (!encoded || (!indexes && n) || !cdfs || !cdf_sizes || !offsets || (!out && n)) return PC_ERR_ARG;
-    if (encoded_len < 8) return PC_ERR_TRUNCATED;
     const size_t nw = encoded_len / 4;
-    size_t p = 2;
     auto word = [&](size_t i) { uint32_t w; std::memcpy(&w, encoded + 4 * i, 4); return w; };
-    uint64_t x = (uint64_t)word(0) | ((uint64_t)word(1) << 32);                       // Rans64DecInit, rans64.h:107-115
     bool trunc = false;
     auto renorm = [&]() { if (x < kRansL) { if (p >= nw) { trunc = true; return; } x = (x << 32) | word(p++); } };
     auto get_bits = [&]() -> int32_t {                                                 // Rans64DecGetBits, rans_interface.cpp:80-96
@@ -151,6 +151,43 @@ extern "C" int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encode
         out[i] = value + offsets[ci];
     }
     return PC_OK;
+}
+}  // namespace
+
+extern "C" int pc_rans_decode_with_indexes(const uint8_t* encoded, size_t encoded_len,
+                                           const int32_t* indexes, size_t n,
+                                           const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                           const int32_t* cdf_sizes, const int32_t* offsets,
+                                           int32_t* out)
+{
+    if (!encoded || (!indexes && n) || !cdfs || !cdf_sizes || !offsets || (!out && n)) return PC_ERR_ARG;
+    if (encoded_len < 8) return PC_ERR_TRUNCATED;
+    uint32_t w0, w1;
+    std::memcpy(&w0, encoded, 4); std::memcpy(&w1, encoded + 4, 4);
+    uint64_t x = (uint64_t)w0 | ((uint64_t)w1 << 32);                                  // Rans64DecInit, rans64.h:107-115
+    size_t p = 2;
+    return rans_decode_core(encoded, encoded_len, x, p, indexes, n, cdfs, n_cdf, cdf_stride, cdf_sizes, offsets, out);
+}
+
+extern "C" int pc_rans_decode_stream(const uint8_t* encoded, size_t encoded_len, uint64_t* state,
+                                     const int32_t* indexes, size_t n,
+                                     const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                     const int32_t* cdf_sizes, const int32_t* offsets, int32_t* out)
+{
+    if (!encoded || !state || (!indexes && n) || !cdfs || !cdf_sizes || !offsets || (!out && n)) return PC_ERR_ARG;
+    if (encoded_len < 8) return PC_ERR_TRUNCATED;
+    if (state[1] == 0) {                                                               // RansDecoder::set_stream, rans_interface.cpp:277-283
+        uint32_t w0, w1;
+        std::memcpy(&w0, encoded, 4); std::memcpy(&w1, encoded + 4, 4);
+        state[0] = (uint64_t)w0 | ((uint64_t)w1 << 32);
+        state[1] = 2;
+    }
+    uint64_t x = state[0];
+    size_t p = (size_t)state[1];
+    if (p < 2 || p > encoded_len / 4) return PC_ERR_ARG;
+    const int r = rans_decode_core(encoded, encoded_len, x, p, indexes, n, cdfs, n_cdf, cdf_stride, cdf_sizes, offsets, out);
+    if (r == PC_OK) { state[0] = x; state[1] = (uint64_t)p; }
+    return r;
 }
 
 extern "C" int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf)
@@ -200,18 +237,74 @@ struct ThreadPool::Impl {
     bool stop = false;
 };
 
+// CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota.  On a multi-GPU node every rank (one per GPU) has
+// its own pool: the CPUs are divided evenly among the local ranks (LOCAL_WORLD_SIZE / LOCAL_RANK as torchrun exports them, or
+// PC_LOCAL_WORLD_SIZE / PC_LOCAL_RANK), each rank takes its own contiguous slice of the allowed CPUs and pins its workers there,
+// so eight ranks do not pile 8 x 16 unpinned threads onto the same cores.
+static std::vector<int> allowed_cpus()
+{
+    std::vector<int> cpus;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c) if (CPU_ISSET(c, &set)) cpus.push_back(c);
+    if (cpus.empty()) { const unsigned hc = std::thread::hardware_concurrency(); for (unsigned c = 0; c < (hc ? hc : 4); ++c) cpus.push_back((int)c); }
+    if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {          // cgroup v2 quota: "max 100000" or "<quota> <period>"
+        char q[32] = {0};
+        long period = 0;
+        if (std::fscanf(f, "%31s %ld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+            const long n = std::max(1L, std::atol(q) / period);
+            if ((size_t)n < cpus.size()) cpus.resize((size_t)n);
+        }
+        std::fclose(f);
+    }
+    return cpus;
+}
+
+static int env_int(const char* a, const char* b, int dflt)
+{
+    for (const char* name : {a, b}) if (const char* v = name ? std::getenv(name) : nullptr) { const int x = std::atoi(v); if (x >= 0) return x; }
+    return dflt;
+}
+
+extern "C" int pc_host_pool_plan(int* n_threads, int* first_cpu, int* n_allowed)
+{
+    // the plan the default pool uses (exported for tests / bench.py's report)
+    const std::vector<int> cpus = allowed_cpus();
+    const int lws = std::max(1, env_int("PC_LOCAL_WORLD_SIZE", "LOCAL_WORLD_SIZE", 1));
+    const int lr = std::min(lws - 1, std::max(0, env_int("PC_LOCAL_RANK", "LOCAL_RANK", 0)));
+    int share = std::max(1, (int)cpus.size() / lws);
+    int n = std::min(share, 16);                                         // one codec serves one GPU: ~16 cores is its share of an 8-GPU node
+    if (const char* e = std::getenv("PC_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }
+    if (n_threads) *n_threads = n;
+    if (first_cpu) *first_cpu = cpus[((size_t)lr * share) % cpus.size()];
+    if (n_allowed) *n_allowed = (int)cpus.size();
+    return PC_OK;
+}
+
 ThreadPool::ThreadPool(int n_threads) : impl_(new Impl)
 {
+    std::vector<int> pin;                                  // CPUs of this rank's slice (empty: no pinning)
     if (n_threads <= 0) {
-        // one codec process serves one GPU; its host share on an 8-GPU node is ~16 cores
-        unsigned hc = std::thread::hardware_concurrency();
-        n_threads = hc ? (int)hc : 4;
+        const std::vector<int> cpus = allowed_cpus();
+        const int lws = std::max(1, env_int("PC_LOCAL_WORLD_SIZE", "LOCAL_WORLD_SIZE", 1));
+        const int lr = std::min(lws - 1, std::max(0, env_int("PC_LOCAL_RANK", "LOCAL_RANK", 0)));
+        const int share = std::max(1, (int)cpus.size() / lws);
+        n_threads = std::min(share, 16);
         if (const char* e = std::getenv("PC_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n_threads = v; }
-        else if (n_threads > 16) n_threads = 16;
+        const char* np = std::getenv("PC_HOST_NO_PIN");
+        if (lws > 1 && !(np && std::atoi(np)))
+            for (int t = 0; t < share; ++t) pin.push_back(cpus[((size_t)lr * share + t) % cpus.size()]);
     }
     n_ = n_threads;
     for (int t = 0; t < n_threads - 1; ++t) {
-        impl_->workers.emplace_back([this] {
+        impl_->workers.emplace_back([this, pin, t] {
+            if (!pin.empty()) {                            // worker t of this rank stays on one CPU of the rank's slice
+                cpu_set_t set;
+                CPU_ZERO(&set);
+                CPU_SET(pin[(size_t)(t + 1) % pin.size()], &set);
+                (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+            }
             Impl& s = *impl_;
             uint64_t seen = 0;
             for (;;) {

@@ -58,12 +58,69 @@ class RansEncoder:
         return rans_encode(symbols, indexes, t)
 
 
+class BufferedRansEncoder:
+    """compressai.ans.BufferedRansEncoder (rans_interface.cpp:99-191): symbols of several encode_with_indexes() calls -- each with
+    its own tables -- go into ONE stream, written by flush().  The reference pushes (start, range) records and pops them in reverse
+    at flush time; that is, byte for byte, one encode over the concatenation, which is what flush() asks the C ABI for (the calls'
+    tables are stacked into one table set and each call's indexes shifted to its rows)."""
+
+    def __init__(self):
+        self._sym, self._idx, self._tabs = [], [], []
+
+    def encode_with_indexes(self, symbols, indexes, cdfs, cdfs_sizes, offsets) -> None:
+        t = cdfs if isinstance(cdfs, CdfTables) else _tables_from_lists(cdfs, cdfs_sizes, offsets)
+        s = np.ascontiguousarray(symbols, np.int32).reshape(-1)
+        i = np.ascontiguousarray(indexes, np.int32).reshape(-1)
+        if s.size != i.size:
+            raise ValueError("`symbols` and `indexes` should have the same size.")
+        base = 0
+        for k, u in enumerate(self._tabs):
+            if u is t:
+                break
+            base += u.cdf.shape[0]
+        else:
+            self._tabs.append(t)
+        self._sym.append(s)
+        self._idx.append(i + base)
+
+    def flush(self) -> bytes:
+        if not self._tabs:
+            t = CdfTables(np.array([[0, 1 << 16]], np.int32), np.array([2], np.int32), np.array([0], np.int32))
+            out = rans_encode(np.zeros(0, np.int32), np.zeros(0, np.int32), t)
+        else:
+            stride = max(u.cdf.shape[1] for u in self._tabs)
+            cdf = np.concatenate([np.pad(u.cdf, ((0, 0), (0, stride - u.cdf.shape[1]))) for u in self._tabs])
+            t = CdfTables(cdf, np.concatenate([u.length for u in self._tabs]), np.concatenate([u.offset for u in self._tabs]))
+            out = rans_encode(np.concatenate(self._sym), np.concatenate(self._idx), t)
+        self._sym, self._idx, self._tabs = [], [], []
+        return out
+
+
 class RansDecoder:
-    """compressai.ans.RansDecoder.decode_with_indexes (rans_interface.cpp:206-275)."""
+    """compressai.ans.RansDecoder (rans_interface.cpp:206-350): decode_with_indexes, and set_stream / decode_stream for a stream
+    that is decoded in several calls (the decoder state lives in this object, as in the reference)."""
+
+    def __init__(self):
+        self._stream = None
+        self._state = None
 
     def decode_with_indexes(self, encoded, indexes, cdfs, cdfs_sizes, offsets):
         t = cdfs if isinstance(cdfs, CdfTables) else _tables_from_lists(cdfs, cdfs_sizes, offsets)
         return rans_decode(encoded, indexes, t).tolist()
+
+    def set_stream(self, encoded) -> None:
+        self._stream = np.frombuffer(bytes(encoded), np.uint8)
+        self._state = np.zeros(2, np.uint64)
+
+    def decode_stream(self, indexes, cdfs, cdfs_sizes, offsets):
+        if self._stream is None:
+            raise ValueError("set_stream() first")
+        t = cdfs if isinstance(cdfs, CdfTables) else _tables_from_lists(cdfs, cdfs_sizes, offsets)
+        i = np.ascontiguousarray(indexes, np.int32).reshape(-1)
+        out = np.empty(i.size, np.int32)
+        check(lib().pc_rans_decode_stream(_ptr(self._stream), self._stream.size, _ptr(self._state), _ptr(i), i.size, _ptr(t.cdf),
+                                          t.cdf.shape[0], t.cdf.shape[1], _ptr(t.length), _ptr(t.offset), _ptr(out)), "rans_decode_stream")
+        return out.tolist()
 
 
 def rans_encode(symbols, indexes, t: CdfTables) -> bytes:

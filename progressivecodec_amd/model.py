@@ -18,6 +18,8 @@ from ._lib import check, lib
 from .arch import CodecConfig, param_spec
 
 _MASK_POL = {"point-based-std": 0, "two-levels": 1, "three-levels-std": 2}
+_PARAM_KINDS = {"conv_w", "conv_b", "deconv_w", "linear_w", "gdn_beta", "gdn_gamma", "relpos_table", "eb_matrix", "eb_bias", "eb_factor",
+                "eb_quantiles"}          # arch.param_spec kinds that are nn.Parameters in the reference (the rest are buffers)
 _DT = {"float32": 0, "int32": 1, "int64": 2}
 
 
@@ -27,10 +29,20 @@ def get_scale_table(min=0.11, max=256, levels=64):
     return torch.exp(torch.linspace(math.log(min), math.log(max), levels))
 
 
-class ChannelProgresssiveWACNN:
+def _module_base():
+    import torch
+    return torch.nn.Module
+
+
+class ChannelProgresssiveWACNN(_module_base()):
+    """A ``torch.nn.Module`` (isinstance checks, ``state_dict()``, ``parameters()``, ``eval()`` ... behave as the caller of the reference
+    expects: SURVEY.md section 8b) whose tensors are host-side copies of what was loaded -- the working weights live packed in
+    HBM inside the native codec object."""
+
     def __init__(self, N=192, M=640, division_dimension=(320, 640), dim_chunk=32, multiple_decoder=True,
                  multiple_encoder=False, multiple_hyperprior=True, mask_policy="two-levels", lmbda_list=(0.0055, 0.04),
                  joiner_policy="res", support_progressive_slices=5, delta_encode=True, device="cuda:0", **kwargs):
+        super().__init__()
         self.cfg = CodecConfig(N=N, M=M, division_dimension=tuple(division_dimension), dim_chunk=dim_chunk,
                                multiple_decoder=multiple_decoder, multiple_encoder=multiple_encoder,
                                multiple_hyperprior=multiple_hyperprior, delta_encode=delta_encode,
@@ -48,20 +60,63 @@ class ChannelProgresssiveWACNN:
         self._sd = None
         self._gc = None
         self._eb = None
+        self._scale_table = None
         self._finalized = False
 
     def __del__(self):
-        h = getattr(self, "_h", None)
+        h = self.__dict__.get("_h", None)
         if h is not None and h.value:
             lib().pc_codec_destroy(h)
             self._h = C.c_void_p()
 
-    # ------------------------------------------------------------------ nn.Module-like surface
-    def eval(self):
+    # ------------------------------------------------------------------ nn.Module surface
+    def to(self, *args, **kwargs):
+        """The codec object is bound to the HIP device it was created on; moving it is not supported (and never needed on the
+        compress()/decompress() path)."""
         return self
 
-    def to(self, device):
-        return self
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training forward() (CHProg_cnn.py:478-682) is out of scope; use forward_single_quality() for rate estimation")
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        """The reference's 1019-key layout (models/cnn.py:195-202), as loaded, with the CDF buffers update() built."""
+        import torch
+        out = OrderedDict() if destination is None else destination
+        if self._sd is None:
+            return out
+        for k, a in self._sd.items():
+            out[prefix + k] = torch.from_numpy(np.array(a, copy=True))
+        for which, p in ((self._gc, "gaussian_conditional"), (self._eb, "entropy_bottleneck")):
+            if which is not None:
+                out[prefix + p + "._quantized_cdf"] = torch.from_numpy(which.cdf.copy())
+                out[prefix + p + "._cdf_length"] = torch.from_numpy(which.length.copy())
+                out[prefix + p + "._offset"] = torch.from_numpy(which.offset.copy())
+        if self._scale_table is not None:
+            out[prefix + "gaussian_conditional.scale_table"] = torch.from_numpy(self._scale_table.copy())
+        return out
+
+    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
+        import torch
+        if self._sd is None:
+            return
+        spec = param_spec(self.cfg)
+        for k, a in self._sd.items():
+            if spec[k][2] in _PARAM_KINDS:
+                yield prefix + k, torch.nn.Parameter(torch.from_numpy(np.array(a, copy=True)), requires_grad=False)
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
+
+    def named_buffers(self, prefix="", recurse=True, remove_duplicate=True):
+        pnames = {k for k, _ in self.named_parameters()}
+        for k, v in self.state_dict().items():
+            if k not in pnames:
+                yield prefix + k, v
+
+    def buffers(self, recurse=True):
+        for _, b in self.named_buffers():
+            yield b
 
     def load_state_dict(self, state_dict, strict=True):
         """models/cnn.py:195-202 / base.py:62-70: accepts the reference's 1019-key state_dict."""
@@ -104,14 +159,20 @@ class ChannelProgresssiveWACNN:
             self._eb = t
 
     def update(self, scale_table=None, force=False):
-        """models/cnn.py:137-142 -> GaussianConditional.update_scale_table / CompressionModel.update."""
+        """models/cnn.py:137-142: ``scale_table`` defaults to get_scale_table(); GaussianConditional.update_scale_table
+        (entropy_models.py:588-597) rebuilds the Gaussian tables only if none are loaded yet or ``force``; then
+        CompressionModel.update (base.py:41-60) does the same for the EntropyBottleneck.  Returns whether anything was rebuilt."""
         if self._sd is None:
             raise ValueError("load_state_dict() first")
         updated = False
         if self._gc is None or force:
-            if scale_table is not None:
-                raise NotImplementedError("a custom scale_table must be part of the state_dict (module buffer)")
-            self._set_tables(0, entropy.gaussian_conditional_tables(self._sd["gaussian_conditional.scale_table"]))
+            st = get_scale_table() if scale_table is None else scale_table
+            st = np.ascontiguousarray([float(v) for v in (st.tolist() if hasattr(st, "tolist") else st)], np.float32)   # _prepare_scale_table :575-576
+            cur = self._scale_table if self._scale_table is not None else self._sd["gaussian_conditional.scale_table"]
+            if st.shape != cur.shape or not np.array_equal(st, cur):
+                check(lib().pc_codec_set_scale_table(self._h, st.ctypes.data_as(C.c_void_p), st.size), "pc_codec_set_scale_table")
+            self._scale_table = st
+            self._set_tables(0, entropy.gaussian_conditional_tables(st))
             updated = True
         if self._eb is None or force:
             self._set_tables(1, entropy.entropy_bottleneck_tables(self._sd))
@@ -129,7 +190,7 @@ class ChannelProgresssiveWACNN:
         check(lib().pc_codec_strings_size(self._h, C.byref(tot), C.byref(n)), "pc_codec_strings_size")
         buf = C.create_string_buffer(max(1, tot.value))
         lens = (C.c_size_t * n.value)()
-        check(lib().pc_codec_copy_strings(self._h, buf, tot.value, lens), "pc_codec_copy_strings")
+        check(lib().pc_codec_copy_strings(self._h, buf, tot.value, lens, n.value), "pc_codec_copy_strings")
         raw = buf.raw
         out, off = [], 0
         for k in lens:
@@ -220,9 +281,9 @@ class ChannelProgresssiveWACNN:
         """CHProg_cnn.py:1002-1198 in eval mode -- what test_epoch / valid_epoch call (training/step.py:215-267).
         Returns {"x_hat", "likelihoods": {"y", "z"}, "masks"}: y [B, 320 or 640, H/16, W/16], z [B, 192, H/64, W/64]; estimated
         bits = -sum(log2(likelihood)).  The auxiliary entries of the reference's dictionary (y_hat, mu, std ...) are not
-        returned.  Training-mode noise and force_enhanced are out of scope."""
+        returned.  Training-mode noise is out of scope.  force_enhanced with quality 0: enhancement path with all-zero masks (:1006,1022,1064)."""
         import torch
-        if training or force_enhanced:
+        if training:
             raise NotImplementedError("only the eval path of forward_single_quality is implemented (SURVEY.md section 8f)")
         mask_pol = self.mask_policy if mask_pol is None else mask_pol
         if mask_pol not in _MASK_POL:
@@ -234,14 +295,15 @@ class ChannelProgresssiveWACNN:
             raise ValueError("H and W must be multiples of 64 (pad as training/step.py:318 does)")
         x = x.to(self.device, torch.float32).contiguous()
         h, w = H // 16, W // 16
-        nch = 640 if quality != 0 else 320
+        enh = quality != 0 or bool(force_enhanced)                               # CHProg_cnn.py:1022,1064
+        nch = 640 if enh else 320
         x_hat = torch.empty((B, 3, H, W), device=self.device, dtype=torch.float32)
         y_lik = torch.empty((B, nch, h, w), device=self.device, dtype=torch.float32)
         z_lik = torch.empty((B, 192, H // 64, W // 64), device=self.device, dtype=torch.float32)
-        masks = torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if quality != 0 else None
+        masks = torch.empty((10, B, 32, h, w), device=self.device, dtype=torch.float32) if enh else None
         P = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         check(lib().pc_codec_forward(self._h, P(x), B, H, W, float(quality), _MASK_POL[mask_pol], P(x_hat), P(y_lik), P(z_lik), P(masks),
-                                     self._stream()), "pc_codec_forward")
+                                     1 if force_enhanced else 0, self._stream()), "pc_codec_forward")
         return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik},
                 "masks": [masks[i] for i in range(10)] if masks is not None else []}
 

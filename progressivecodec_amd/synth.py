@@ -63,7 +63,7 @@ def synthetic_state_dict(cfg: CodecConfig = CodecConfig(), seed: int = 0, as_tor
             if kh == 5:
                 std *= 0.8
             w = g.standard_normal(shape) * std
-            if name == "g_a.7.weight":
+            if name in ("g_a.7.weight", "g_a.0.7.weight", "g_a.1.7.weight"):
                 w *= AMP_Y       # latent amplitude: symbols of a few units
             if name.startswith("h_a.8"):
                 w *= AMP_Z       # hyper-latent z spread over a few integers

@@ -141,3 +141,59 @@ def test_arch_spec_matches_reference_state_dict_layout():
                    if kind not in ("table", "pedestal", "beta_bound", "gamma_bound", "relpos_index", "eb_target",
                                    "likelihood_bound", "scale_bound", "scale_table"))
     assert n_params == 152137398                                 # authors' log, SURVEY.md section 6
+
+
+def eb_tables():
+    t = tables_npz()
+    return entropy.CdfTables(t["eb_cdf"], t["eb_len"], t["eb_off"])
+
+
+def test_streaming_ans_surface_known_answers_from_reference():
+    """BufferedRansEncoder.encode_with_indexes (several calls, different tables) + flush and RansDecoder.set_stream +
+    decode_stream (rans_interface.cpp:99-191, 277-350) against vectors made by the reference's own module
+    (tests/golden/make_golden_rans_stream.py): same bytes, same symbols call by call."""
+    tabs = {"gc": gc_tables(), "eb": eb_tables()}
+    for k in json.load(open(os.path.join(GOLD, "kat_rans_stream.json"))):
+        enc = entropy.BufferedRansEncoder()
+        for ch in k["chunks"]:
+            assert enc.encode_with_indexes(ch["symbols"], ch["indexes"], tabs[ch["table"]], None, None) is None
+        data = enc.flush()
+        assert data.hex() == k["encoded_hex"], k["name"]
+        assert enc.flush() == entropy.rans_encode([], [], gc_tables())          # flushed: the encoder is empty again
+        dec = entropy.RansDecoder()
+        dec.set_stream(bytes.fromhex(k["encoded_hex"]))
+        for ch in k["chunks"]:
+            assert dec.decode_stream(ch["indexes"], tabs[ch["table"]], None, None) == ch["symbols"], k["name"]
+    # list-of-lists tables (the reference's calling convention) and the error paths
+    enc = entropy.BufferedRansEncoder()
+    enc.encode_with_indexes([0, 1, -1], [0] * 3, [[0, 8192, 57344, 61440, 65536]], [5], [-1])
+    enc.encode_with_indexes([0, 7, -4], [0] * 3, [[0, 8192, 57344, 61440, 65536]], [5], [-1])
+    assert enc.flush().hex() == "a141ad217f1cc771"                              # == the one-call KAT of SURVEY.md section 8c
+    with pytest.raises(ValueError):
+        entropy.RansDecoder().decode_stream([0], gc_tables(), None, None)       # no stream set
+    d = entropy.RansDecoder()
+    d.set_stream(b"\x00" * 4)
+    with pytest.raises(PcodecError) as ei:
+        d.decode_stream([0], gc_tables(), None, None)
+    assert ei.value.code == -4
+
+
+def test_host_pool_plan_divides_cpus_among_local_ranks():
+    """pc_host_pool_plan: threads = min(16, allowed CPUs / local ranks); a rank's slice starts at its own first CPU (run in
+    subprocesses: the plan reads LOCAL_WORLD_SIZE / LOCAL_RANK from the environment)."""
+    import subprocess
+    import sys
+    code = ("import ctypes as C; from progressivecodec_amd._lib import lib; n, f, a = C.c_int(), C.c_int(), C.c_int();"
+            "lib().pc_host_pool_plan(C.byref(n), C.byref(f), C.byref(a)); print(n.value, f.value, a.value)")
+    def plan(**env):
+        e = dict(os.environ, **{k: str(v) for k, v in env.items()})
+        e.pop("PC_HOST_THREADS", None)
+        return tuple(map(int, subprocess.check_output([sys.executable, "-c", code], env=e, cwd=ROOT).split()))
+    n1, f1, a = plan(LOCAL_WORLD_SIZE=1, LOCAL_RANK=0)
+    assert n1 == min(16, a) and a >= 1
+    if a >= 2:
+        n2a, f2a, _ = plan(LOCAL_WORLD_SIZE=2, LOCAL_RANK=0)
+        n2b, f2b, _ = plan(LOCAL_WORLD_SIZE=2, LOCAL_RANK=1)
+        assert n2a == n2b == min(16, a // 2) and f2a != f2b
+    n8, _, _ = plan(LOCAL_WORLD_SIZE=8, LOCAL_RANK=3)
+    assert n8 == max(1, min(16, a // 8))
