@@ -281,13 +281,18 @@ class RefCodec:
         beta, gamma = gdn_params(self.sd, p)
         return self.ops.gdn(x, beta, gamma, inverse)
 
-    def g_a(self, x):                                   # models/cnn.py:34-44
-        x = self._gdn(self._c(x, "g_a.0", 2), "g_a.1")
-        x = self._gdn(self._c(x, "g_a.2", 2), "g_a.3")
-        x = self._wam(x, "g_a.4", 8, 4)
-        x = self._gdn(self._c(x, "g_a.5", 2), "g_a.6")
-        x = self._c(x, "g_a.7", 2)
-        return self._wam(x, "g_a.8", 4, 2)
+    def _g_a_net(self, x, p):                           # models/cnn.py:34-44
+        x = self._gdn(self._c(x, p + ".0", 2), p + ".1")
+        x = self._gdn(self._c(x, p + ".2", 2), p + ".3")
+        x = self._wam(x, p + ".4", 8, 4)
+        x = self._gdn(self._c(x, p + ".5", 2), p + ".6")
+        x = self._c(x, p + ".7", 2)
+        return self._wam(x, p + ".8", 4, 2)
+
+    def g_a(self, x):
+        if "g_a.0.0.weight" in self.sd:                 # multiple_encoder: CHProg_cnn.py:131-144, used at :691-697
+            return torch.cat([self._g_a_net(x, "g_a.0"), self._g_a_net(x, "g_a.1")], 1)
+        return self._g_a_net(x, "g_a")
 
     def g_s(self, k, y):                                # models/CHProg_cnn.py:149-161
         p = f"g_s.{k}"
@@ -369,8 +374,9 @@ class RefCodec:
         return [base[i]] + (enh[i - min(MAX_SUPPORT, i):i] if i > 0 else [])
 
     # ---- compress / decompress
-    def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None, cust_map=None):
-        """ChannelProgresssiveWACNN.compress, models/CHProg_cnn.py:686-847."""
+    def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None, cust_map=None, force_enhanced=False):
+        """ChannelProgresssiveWACNN.compress, models/CHProg_cnn.py:686-847.  force_enhanced (forward_single_quality only,
+        :1006,1022,1064): at quality 0 still run both hyper-priors and the enhancement chain (all-zero masks)."""
         T = taps if taps is not None else {}
         y = self.g_a(x)                                                     # :692
         z = self.h_a(y)                                                     # :700
@@ -380,7 +386,7 @@ class RefCodec:
         z_idx = self._eb_indexes(B, zh, zw)
         z_strings = self._encode(z_sym, z_idx, self.eb)
         z_hat = z_sym.float() + med                                         # :704 -> entropy_models.py:517-522,289
-        lm, ls = self._hyper(z_hat, quality)
+        lm, ls = self._hyper(z_hat, 1.0 if force_enhanced else quality)
         T.update(y=y, z=z, z_sym=z_sym, latent_means=lm, latent_scales=ls)
         y_slices = y.chunk(NS1, 1)
         y_strings, masks, base = [], [], []
@@ -397,7 +403,7 @@ class RefCodec:
             y_hat = self._lrp("lrp_transforms", i, mean_support, y_hat)
             base.append(y_hat)
             T[f"b{i}"] = dict(mu=mu, scale=scale, idx=idx, sym=sym, y_hat=y_hat)
-        if quality <= 0:                                                    # :766-767
+        if quality <= 0 and not force_enhanced:                             # :766-767
             return {"strings": [y_strings, z_strings], "shape": torch.Size([zh, zw]), "masks": masks}
         enh = []
         cm = cust_map.chunk(NS0, 1) if cust_map is not None else None       # :721-722
@@ -456,11 +462,11 @@ class RefCodec:
         lik = torch.max(lik, torch.tensor(1e-9, dtype=torch.float32))
         return lik.reshape(C, B, h, w).permute(1, 0, 2, 3).contiguous()
 
-    def forward_single_quality(self, x, quality, mask_pol="point-based-std"):
+    def forward_single_quality(self, x, quality, mask_pol="point-based-std", force_enhanced=False):
         """ChannelProgresssiveWACNN.forward_single_quality in eval mode, models/CHProg_cnn.py:1002-1198: the chain of compress()
         (same mu / scale / mask / round / LRP per slice, :1033-1160) with likelihoods instead of entropy coding, then g_s."""
         T = {}
-        self.compress(x, quality, mask_pol, taps=T)
+        out = self.compress(x, quality, mask_pol, taps=T, force_enhanced=force_enhanced)
         med = self.medians.view(1, -1, 1, 1)
         z_lik = self._eb_likelihood(T["z_sym"].float() + med)                       # compute_hyperprior :400
         liks, y_hat = [], []
@@ -469,14 +475,14 @@ class RefCodec:
             outputs = t["sym"].float() + t["mu"]                                    # quantize(.., "dequantize", means), :137-139,:159-165
             liks.append(self._gc_likelihood(outputs - t["mu"], t["scale"]))         # values = inputs - means (float32: not exactly sym)
             y_hat.append(t["y_hat"])
-        if quality == 0:                                                            # :1063-1080
-            return {"x_hat": self.g_s(0, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}}
+        if quality == 0 and not force_enhanced:                                     # :1063-1080
+            return {"x_hat": self.g_s(0, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}, "masks": []}
         y_hat = []
         for i in range(NS0):                                                        # :1150 (scale * block_mask, no means)
             t = T[f"e{i}"]
             liks.append(self._gc_likelihood(t["sym"].float(), t["scale"] * t["mask"]))
             y_hat.append(t["y_hat"])
-        return {"x_hat": self.g_s(1, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}}
+        return {"x_hat": self.g_s(1, torch.cat(y_hat, 1)).clamp_(0, 1), "likelihoods": {"y": torch.cat(liks, 1), "z": z_lik}, "masks": out["masks"]}
 
     def decompress(self, strings, shape, quality, mask_pol="point-based-std", taps=None, cust_map=None):
         """ChannelProgresssiveWACNN.decompress, models/CHProg_cnn.py:849-999."""

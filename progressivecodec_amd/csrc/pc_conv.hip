@@ -798,24 +798,44 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
         b_q[i] = sl ^ pc_swz<KQ>(row);
         b_off[i] = (n0 + row < p.Cout) ? (row * p.Cin + 4 * b_q[i]) * 4 : OOB;
     }
-    // ---- run table (one entry per (tap, input segment)), built once per block
+    // ---- run table, built once per block: one entry per (tap, input segment), and a second one for the segment's last nch % BK
+    // channels when there are any -- a short chunk is then a run of its own whose per-piece offsets (computed at the run boundary)
+    // already mask the absent k-quads, and the chunk loop never has to look at the channel count
     pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
-    const int nruns = T * p.nseg;
+    int runs_per_tap = 0;
+    for (int sg = 0; sg < p.nseg; ++sg) runs_per_tap += (p.seg[sg].nch >= BK ? 1 : 0) + (p.seg[sg].nch % BK ? 1 : 0);
+    const int nruns = T * runs_per_tap;
     for (int r = threadIdx.x; r < nruns; r += NTH) {
-        const int t = r / p.nseg, sg = r - t * p.nseg;
-        int cbase = 0;
-        for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
+        const int t = r / runs_per_tap;
+        int rr = r - t * runs_per_tap, sg = 0, cbase = 0, ch0 = 0, nch = 0;
+        for (;; ++sg) {                                    // locate run rr of this tap: (segment, full part or remainder)
+            const int full = p.seg[sg].nch / BK * BK, rem = p.seg[sg].nch - full;
+            const int here = (full ? 1 : 0) + (rem ? 1 : 0);
+            if (rr < here) { const bool is_rem = full ? rr == 1 : true; ch0 = is_rem ? full : 0; nch = is_rem ? rem : full; break; }
+            rr -= here; cbase += p.seg[sg].nch;
+        }
         pc_run d;
-        d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
-        d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
-        d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
+        d.ld = p.seg[sg].ld; d.nch = nch; d.tap = t; d.pad = 0;
+        d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld + ch0;
+        d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase + ch0;
         runs[r] = d;
     }
     __syncthreads();                                       // no DMA in flight yet: a plain barrier is fine
     const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
-    uint32_t ra_lo = 0, ra_hi = 0, rb_lo = 0, rb_hi = 0;
-    int a_off[AIN];
+    // The steady-state instruction stream of a chunk holds NO VALU instruction: an MFMA chain on one accumulator only keeps its
+    // 64-cycle cadence while nothing but MFMAs, LDS reads, LDS-DMAs and scalar instructions sit between two dependent MFMAs -- a
+    // single v_add / v_cndmask / v_readfirstlane there costs the wave ~60 cycles (tools/mfma_issue_probe.hip: 124 vs 64 cycles per
+    // MFMA with one VALU in between).  Hence: the two buffer descriptors live in SGPRs from run boundary to run boundary, the
+    // per-piece offsets are the run's own (a segment's short last chunk is a run of its own: no per-chunk select), and the operand
+    // read addresses are fixed registers with the stage as an immediate offset (the chunk body is instantiated per stage).
+    auto mk = [](uint64_t a) { return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a), 0, 0x7fffffff, 0x00020000); };
+    __amdgpu_buffer_rsrc_t rsrc_a = mk(0), rsrc_b = mk(0);
+    int ea[AIN], eb[BIN];                                  // this run's per-piece offsets: tap validity and (short runs) absent k-quads folded in
     int run = 0, c_left = 0, koff = 0;
+    if (DBG & 4) {
+#pragma unroll
+        for (int i = 0; i < BIN; ++i) b_off[i] = OOB;
+    }
     auto enter_run = [&](int r) {                          // hand-written LDS reads: see conv_igemm_dma_kernel
         u32x4 lo, hi;
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
@@ -824,29 +844,22 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
         const uint64_t pw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.z);
         const int d_ld = __builtin_amdgcn_readfirstlane((int)hi.x), d_nch = __builtin_amdgcn_readfirstlane((int)hi.y);
         const int d_tap = __builtin_amdgcn_readfirstlane((int)hi.z);
-        const float* d_a = reinterpret_cast<const float*>(pa) + pix0 * d_ld;
-        const float* d_w = reinterpret_cast<const float*>(pw) + (int64_t)n0 * p.Cin;
-        ra_lo = (uint32_t)(uintptr_t)d_a; ra_hi = (uint32_t)((uintptr_t)d_a >> 32);
-        rb_lo = (uint32_t)(uintptr_t)d_w; rb_hi = (uint32_t)((uintptr_t)d_w >> 32);
+        // (readfirstlane once more on the finished addresses: hipcc must SEE that the descriptors are wave-uniform, or it keeps them in
+        // VGPRs and wraps every DMA in a waterfall loop)
+        auto uni64 = [](uint64_t v) {
+            return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+        };
+        rsrc_a = mk(uni64(pa + (uint64_t)(pix0 * d_ld) * 4u));
+        rsrc_b = mk(uni64(pw + (uint64_t)((int64_t)n0 * p.Cin) * 4u));
         c_left = d_nch; koff = 0;
 #pragma unroll
-        for (int i = 0; i < AIN; ++i) a_off[i] = ((a_mask[i] >> d_tap) & 1u) ? (a_rel[i] * d_ld + 4 * a_q[i]) * 4 : OOB;
+        for (int i = 0; i < AIN; ++i) ea[i] = (((a_mask[i] >> d_tap) & 1u) && 4 * a_q[i] < d_nch && !(DBG & 4)) ? (a_rel[i] * d_ld + 4 * a_q[i]) * 4 : OOB;
+#pragma unroll
+        for (int i = 0; i < BIN; ++i) eb[i] = (4 * b_q[i] < d_nch) ? b_off[i] : OOB;
     };
     enter_run(0);
-    auto mk = [](uint32_t lo, uint32_t hi) {
-        const uint64_t a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a), 0, 0x7fffffff, 0x00020000);
-    };
-    // state of the chunk being issued: effective per-piece offsets (a partial last chunk of a segment masks its absent quads)
-    int ea[AIN], eb[BIN];
-    auto prepare = [&]() {
-        const bool full = c_left >= BK;
-#pragma unroll
-        for (int i = 0; i < AIN; ++i) ea[i] = ((full || 4 * a_q[i] < c_left) && !(DBG & 4)) ? a_off[i] : OOB;
-#pragma unroll
-        for (int i = 0; i < BIN; ++i) eb[i] = ((full || 4 * b_q[i] < c_left) && !(DBG & 4)) ? b_off[i] : OOB;
-    };
-    auto piece = [&](int q, int stage, const __amdgpu_buffer_rsrc_t& rsrc_a, const __amdgpu_buffer_rsrc_t& rsrc_b) {
+    // piece q of the chunk being fetched, into stage `stage`
+    auto piece = [&](int q, int stage) {
         if (DBG & 2) return;
         float4* base = smem + stage * STAGE;
         if (q < AIN)
@@ -881,7 +894,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     // Operand reads are hand-written ds_read_b128: behind a plain LDS load hipcc places `s_waitcnt vmcnt(0)` whenever the wave has an
     // LDS-DMA in flight (it must assume the read aliases the DMA's destination), which would drain the prefetch pipeline at every
     // read.  The stage being read was retired by the counted vmcnt + barrier at the top of the chunk; the DMAs in flight target
-    // another stage.  Per-lane byte addresses of the NG k-groups' pieces (stage 0), tiles by immediate offsets.
+    // another stage.  Per-lane byte addresses of the NG k-groups' pieces (stage 0); stage and tile are immediate offsets.
     const uint32_t smem_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
     uint32_t a_addr[NG], b_addr[NG];
 #pragma unroll
@@ -889,25 +902,21 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
         a_addr[g] = smem_lds + (uint32_t)(am * KQ + ((2 * g + half) ^ a_swz)) * 16u;
         b_addr[g] = smem_lds + (uint32_t)(A_PIECES + bn * KQ + ((2 * g + half) ^ b_swz)) * 16u;
     }
-    // one chunk: NL live column tiles; ISSUE: place the NI pieces of the chunk being fetched behind MFMAs
-    auto chunk = [&](auto nl_tag, auto issue_tag, int st_c, int st_i) {
+    constexpr bool IMM_STAGE = (S - 1) * STAGE * 16 + (TM > TN ? TM : TN) * 32 * KQ * 16 < 65536;   // ds_read's offset field is 16 bits
+    // one chunk: NL live column tiles; ISSUE: place the NI pieces of the chunk being fetched behind MFMAs; ST: the stage being read
+    auto chunk = [&](auto nl_tag, auto issue_tag, auto st_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         constexpr bool ISSUE = decltype(issue_tag)::value;
+        constexpr int ST = decltype(st_tag)::value, ST_I = (ST + S - 1) % S;   // chunk c in stage ST; chunk c + S - 1 goes where c - 1 was
         constexpr int NS = NG * 4 * TM * (NL > 0 ? NL : 1);           // MFMA slots of this variant
-        const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
-        if (ISSUE) prepare();
-        if (NL == 0) {                                                // a wave with no live column still loads its share
-            if (ISSUE) {
+        if (ISSUE && (NL == 0 || (DBG & 16))) {                       // no MFMAs to hide behind: all pieces now
 #pragma unroll
-                for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
-            }
-            return;
+            for (int q = 0; q < NI; ++q) piece(q, ST_I);
         }
-        if (ISSUE && (DBG & 16)) {
-#pragma unroll
-            for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
-        }
-        const uint32_t st_off = (uint32_t)st_c * (uint32_t)(STAGE * 16);
+        if (NL == 0) return;                                          // a wave with no live column only loads its share
+        constexpr bool interleave = ISSUE && !(DBG & 16);
+        const uint32_t st_off = IMM_STAGE ? 0u : (uint32_t)(ST * STAGE * 16);
+        constexpr int IMM = IMM_STAGE ? ST * STAGE * 16 : 0;
         f32x4 va[2][TM], vb[2][TN];
         if (DBG & 8) {
 #pragma unroll
@@ -922,9 +931,9 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             if (DBG & 8) return;
             const uint32_t aa = a_addr[g] + st_off, ba = b_addr[g] + st_off;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va[g & 1][i]) : "v"(aa), "n"(i * 32 * KQ * 16));
+            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va[g & 1][i]) : "v"(aa), "n"(IMM + i * 32 * KQ * 16));
 #pragma unroll
-            for (int j = 0; j < NL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb[g & 1][j]) : "v"(ba), "n"(j * 32 * KQ * 16));
+            for (int j = 0; j < NL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb[g & 1][j]) : "v"(ba), "n"(IMM + j * 32 * KQ * 16));
         };
         reads(0);
 #pragma unroll
@@ -957,45 +966,62 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
                         if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i][s], xb[j][s], acc[i][j], 0, 0, 0);
-                        if (ISSUE && !(DBG & 16)) {
+                        if (interleave) {
                             const int slot_ix = ((g * 4 + s) * TM + i) * NL + j;      // compile-time after unrolling
 #pragma unroll
                             for (int q = 0; q < NI; ++q)
-                                if ((q * NS) / NI == slot_ix) { __builtin_amdgcn_sched_barrier(0); piece(q, st_i, rsrc_a, rsrc_b); __builtin_amdgcn_sched_barrier(0); }
+                                if ((q * NS) / NI == slot_ix) { __builtin_amdgcn_sched_barrier(0); piece(q, ST_I); __builtin_amdgcn_sched_barrier(0); }
                         }
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // The chunk loop is unrolled by S so that the stage is a compile-time constant of each body (immediate LDS offsets, no address
+    // VALU) while the accumulators stay in ONE register set along a straight-line path (a per-chunk switch over the stage made hipcc
+    // ping-pong them between two AGPR sets with 16 v_accvgpr_mov per chunk).
     auto kloop = [&](auto nl_tag) {
-        int st_c = 0, st_i = 0, issued = 0;
-        // prologue: chunks 0 .. S-2 in flight
-        for (; issued < S - 1 && issued < nchunks; ++issued) {
-            const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
-            prepare();
+        int st_i = 0, issued = 0;
+        for (; issued < S - 1 && issued < nchunks; ++issued) {       // prologue: chunks 0 .. S-2 in flight
 #pragma unroll
-            for (int q = 0; q < NI; ++q) piece(q, st_i, rsrc_a, rsrc_b);
+            for (int q = 0; q < NI; ++q) piece(q, st_i);
             advance();
             st_i = st_i + 1 == S ? 0 : st_i + 1;
         }
-        const int n_main = nchunks - (S - 1);
-        int c = 0;
-        for (; c < n_main; ++c) {
+        const int n_main = nchunks - (S - 1) > 0 ? nchunks - (S - 1) : 0;
+        auto step = [&](auto st_tag) {                                // chunk c < n_main: fetch chunk c + S - 1 behind its MFMAs
             pc_wait_vm<NI * (S - 2)>();
             __builtin_amdgcn_s_barrier();
-            chunk(nl_tag, std::true_type{}, st_c, st_i);
+            chunk(nl_tag, std::true_type{}, st_tag);
             advance();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            st_c = st_c + 1 == S ? 0 : st_c + 1;
-            st_i = st_i + 1 == S ? 0 : st_i + 1;
-        }
-        for (; c < nchunks; ++c) {                                    // the last S-1 chunks: nothing left to fetch
-            pc_wait_chunks<NI, S - 2>(nchunks - 1 - c);
+        };
+        auto tail = [&](auto st_tag, int left_after) {                // one of the last S-1 chunks: nothing left to fetch
+            pc_wait_chunks<NI, S - 2>(left_after);
             __builtin_amdgcn_s_barrier();
-            chunk(nl_tag, std::false_type{}, st_c, st_i);
+            chunk(nl_tag, std::false_type{}, st_tag);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            st_c = st_c + 1 == S ? 0 : st_c + 1;
+        };
+        int c = 0;
+        for (; c + S <= n_main; c += S) {
+            step(std::integral_constant<int, 0>{});
+            step(std::integral_constant<int, 1 % S>{});
+            if constexpr (S >= 3) step(std::integral_constant<int, 2 % S>{});
+            if constexpr (S >= 4) step(std::integral_constant<int, 3 % S>{});
         }
+        // what is left (fewer than S main chunks, then the S-1 tail chunks): c is a multiple of S, so leftover t sits in stage t % S
+        auto rest = [&](auto t_tag) {
+            constexpr int t = decltype(t_tag)::value;
+            if (c + t < nchunks) {
+                if (c + t < n_main) step(std::integral_constant<int, t % S>{});
+                else tail(std::integral_constant<int, t % S>{}, nchunks - 1 - (c + t));
+            }
+        };
+        rest(std::integral_constant<int, 0>{});
+        rest(std::integral_constant<int, 1>{});
+        if constexpr (2 * S - 2 > 2) rest(std::integral_constant<int, 2>{});
+        if constexpr (2 * S - 2 > 3) rest(std::integral_constant<int, 3>{});
+        if constexpr (2 * S - 2 > 4) rest(std::integral_constant<int, 4>{});
+        if constexpr (2 * S - 2 > 5) rest(std::integral_constant<int, 5>{});
     };
     if (DBG & 64) tl[1] = __builtin_amdgcn_s_memrealtime();
     if (nlive == TN) kloop(std::integral_constant<int, TN>{});
@@ -1240,7 +1266,7 @@ hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
     constexpr int BM = 64 * TM, BN = 64 * TN;
     int tmax = 0;
     for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
-    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
+    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * 2 * sizeof(pc_run);
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);
     auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ, DBG>;
@@ -1345,8 +1371,13 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         static const int tn_env = [] { const char* v = std::getenv("PC_CONV_TN"); return v ? std::atoi(v) : 0; }();
         e = hipErrorInvalidValue;
         if (kern_env == 1) {
-            int tm = tm_env ? tm_env : 1, tn = tn_env ? tn_env : 1;
-            const int Su = s_env ? s_env : (chunks <= 8 ? 2 : 3);
+            // Tile choice (tools/conv_tune.py sweeps, profiles/r02_sweep3_*): 64x64 blocks (one 32x32 accumulator per wave) with three
+            // stages for the M = 8192 slice-chain GEMMs, where the number of workgroups is what fills the chip; 128x64 blocks (two
+            // accumulators per wave, 25 % less L2->LDS traffic, half the DMA / ds_read instructions per MFMA) with two stages once
+            // there are >= 6 of the smaller blocks per CU anyway (the high-resolution layers of g_a / g_s: +3..6 %).
+            const long nb64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
+            int tm = tm_env ? tm_env : (nb64 >= 1536 ? 2 : 1), tn = tn_env ? tn_env : 1;
+            const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
             const int ab = (p.dbg & 64) ? 0 : (p.dbg & 15);                   // ablation builds of the 64x64 three-stage instantiation
             if (p.square) e = launch_uni<32, 2, 1, 1, true>(p, stream);
             else if (ab == 1) e = launch_uni<32, 3, 1, 1, false, 1>(p, stream);

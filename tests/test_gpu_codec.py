@@ -510,3 +510,148 @@ def test_error_behaviour_of_the_wider_entry_points():
     bad = [[s[0][:6]] for s in d[1]["strings"][0]]
     with pytest.raises(PcodecError):
         net.decompress_levels([d[0]["strings"], [bad, d[1]["strings"][1]]], d[0]["shape"], [0, 0.5])
+
+
+# ------------------------------------------------------------------ multiple_encoder=True and force_enhanced (VERDICT r01 missing 2 / 6)
+def _multienc_gpu():
+    import functools
+    from tests.test_oracle_vs_golden import multienc_sd
+    global _ME_NET
+    try:
+        return _ME_NET
+    except NameError:
+        from progressivecodec_amd import ChannelProgresssiveWACNN
+        _ME_NET = ChannelProgresssiveWACNN(device="cuda:0", multiple_encoder=True)
+        _ME_NET.load_state_dict(multienc_sd())
+        return _ME_NET
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_multiple_encoder_bit_exact_vs_oracle_and_reference_goldens(idx):
+    """Two analysis transforms, y = cat(g_a[0](x), g_a[1](x)) (CHProg_cnn.py:131-144,691-697): GPU == contract oracle on every
+    string, mask and x_hat; hyper-latent strings and mask popcounts equal the REAL reference's (tests/golden/multienc.json), bpp / PSNR
+    within the flip tolerances (1e-4 dB when no y string differs)."""
+    import json
+    import os
+    from oracle.codec_ref import RefCodec
+    from tests.test_oracle_vs_golden import multienc_sd
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "multienc.json")))["multienc"][idx]
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    net = _multienc_gpu()
+    out = net.compress(x.cuda(), c["quality"], "point-based-std")
+    orc = RefCodec(multienc_sd(), "cdet")
+    ref = orc.compress(x, c["quality"])
+    assert out["strings"][1] == ref["strings"][1] and out["strings"][0] == ref["strings"][0]
+    for m, rm in zip(out["masks"], ref["masks"]):
+        assert np.array_equal(m.cpu().numpy(), rm.numpy())
+    dec = net.decompress(out["strings"], out["shape"], c["quality"], "point-based-std")["x_hat"].cpu()
+    rdec = orc.decompress(ref["strings"], ref["shape"], c["quality"])["x_hat"]
+    assert np.array_equal(dec.numpy().view(np.uint32), rdec.numpy().view(np.uint32))
+    assert [sha(s) for s in out["strings"][1]] == c["z_sha"]
+    assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    first = flip_report(out["strings"][0], c["y_sha"], c["B"])
+    psnr = psnr_of(x, dec.clamp(0, 1))
+    print(f"{c['case']} q={c['quality']}: first diverging slice per image {first}; psnr {psnr:.6f} (ref {c['psnr']:.6f})")
+    assert abs(psnr - c["psnr"]) <= (NORTH_STAR_PSNR_TOL_DB if all(f is None for f in first) else PSNR_TOL_DB)
+    assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) <= (0 if all(f is None for f in first) else BPP_TOL * c["bpp"])
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_force_enhanced_vs_oracle_and_reference_goldens(idx):
+    """forward_single_quality(quality=0, force_enhanced=True) (CHProg_cnn.py:1006,1022,1064): x_hat bit-exact vs the contract oracle,
+    likelihoods within one float32 ulp; estimated bits within 2e-3 of the REAL reference's, 640 likelihood channels, all-zero masks."""
+    import json
+    import os
+    c = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "multienc.json")))["forced"][idx]
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    net = gpu_codec()
+    out = net.forward_single_quality(x.cuda(), 0, "point-based-std", force_enhanced=True)
+    ref = oracle_codec("cdet").forward_single_quality(x, 0, force_enhanced=True)
+    ly, ry = out["likelihoods"]["y"].cpu(), ref["likelihoods"]["y"]
+    assert list(ly.shape) == c["y_shape"]
+    assert np.array_equal(out["x_hat"].cpu().numpy().view(np.uint32), ref["x_hat"].numpy().view(np.uint32))
+    assert ((ly - ry).abs() / ry).max().item() <= LIK_RTOL
+    assert all(int(m.sum().item()) == 0 for m in out["masks"]) and len(out["masks"]) == 10
+    by = float(-torch.log2(ly.double()).sum())
+    assert abs(by - c["bits_y"]) <= 2e-3 * c["bits_y"]
+    assert abs(psnr_of(x, out["x_hat"].cpu()) - c["psnr"]) <= PSNR_TOL_DB
+    plain = net.forward_single_quality(x.cuda(), 0, "point-based-std")
+    assert plain["likelihoods"]["y"].shape[1] == 320 and torch.equal(plain["likelihoods"]["y"], out["likelihoods"]["y"][:, :320])
+
+
+def test_module_surface_and_update_scale_table():
+    """nn.Module surface and update(scale_table=..., force=...) (models/cnn.py:137-142, entropy_models.py:588-597)."""
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from progressivecodec_amd.model import get_scale_table
+    from tests.util import synth_sd
+    net = ChannelProgresssiveWACNN(device="cuda:0")
+    assert isinstance(net, torch.nn.Module) and net.eval() is net
+    net.load_state_dict(synth_sd())
+    sd = net.state_dict()
+    assert len(sd) == 1019 and torch.equal(sd["g_a.0.weight"], synth_sd()["g_a.0.weight"])
+    assert sum(p.numel() for p in net.parameters()) == 152137398                 # authors' log (SURVEY.md section 6)
+    assert net.update() is False                                                 # tables came with the state dict: nothing rebuilt
+    x = inputs(1, 64, 64, 3).cuda()
+    a = net.compress(x, 0.5, "point-based-std")
+    assert net.update(force=True) is True                                        # rebuilt from get_scale_table(): identical tables
+    b = net.compress(x, 0.5, "point-based-std")
+    assert a["strings"] == b["strings"]
+    # a coarser custom table: different indexes / strings, still decodable; the oracle with the same table agrees bit for bit
+    coarse = get_scale_table(0.11, 256, 32)
+    assert net.update(scale_table=coarse, force=True) is True
+    c = net.compress(x, 0.5, "point-based-std")
+    assert c["strings"][0] != a["strings"][0] and c["strings"][1] == a["strings"][1]
+    from oracle.codec_ref import RefCodec, gaussian_conditional_tables
+    sd2 = dict(synth_sd())
+    sd2["gaussian_conditional.scale_table"] = coarse
+    orc = RefCodec(sd2, "cdet", gc_tables=gaussian_conditional_tables(coarse))
+    r = orc.compress(x.cpu(), 0.5)
+    assert c["strings"][0] == r["strings"][0]
+    xh = net.decompress(c["strings"], c["shape"], 0.5, "point-based-std")["x_hat"].cpu()
+    assert np.array_equal(xh.numpy().view(np.uint32), orc.decompress(r["strings"], r["shape"], 0.5)["x_hat"].numpy().view(np.uint32))
+    assert torch.equal(net.state_dict()["gaussian_conditional.scale_table"], coarse)
+
+
+def test_quality_zero_string_count_matches_num_slices():
+    """after compress at quality 0 the bulk-copy ABI reports 10*B + B strings, like pc_codec_num_slices."""
+    import ctypes as C
+    from progressivecodec_amd._lib import lib
+    net = gpu_codec()
+    B = 2
+    out = net.compress(inputs(B, 64, 64, 9).cuda(), 0.0, "point-based-std")
+    tot, n = C.c_size_t(), C.c_int()
+    assert lib().pc_codec_strings_size(net._h, C.byref(tot), C.byref(n)) == 0
+    assert lib().pc_codec_num_slices(net._h) == 10 and n.value == 10 * B + B and len(out["strings"][0]) == 10
+    buf = C.create_string_buffer(tot.value)
+    lens = (C.c_size_t * n.value)()
+    assert lib().pc_codec_copy_strings(net._h, buf, tot.value, lens, n.value - 1) == -3         # lens too short: PC_ERR_BUFFER
+    assert lib().pc_codec_copy_strings(net._h, buf, tot.value, lens, n.value) == 0
+
+
+def test_row_table_cache_is_bounded_and_freed():
+    """distinct image geometries must not grow HBM without bound; destroying a codec returns its memory."""
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from tests.util import synth_sd
+    torch.cuda.synchronize()
+    net = ChannelProgresssiveWACNN(device="cuda:0")
+    net.load_state_dict(synth_sd())
+    x0 = torch.rand(1, 3, 64, 64).cuda()
+    net.compress(x0, 0.5, "point-based-std")
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    sizes = [(64 * a, 64 * b) for a in range(1, 8) for b in range(1, 8)]          # 49 geometries, largest first below
+    big = max(sizes, key=lambda s: s[0] * s[1])
+    net.compress(torch.rand(1, 3, *big).cuda(), 0.5, "point-based-std")           # workspace grows to its maximum once
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info()[0]
+    for H, W in sizes:
+        o = net.compress(torch.rand(1, 3, H, W).cuda(), 0.5, "point-based-std")
+        net.decompress(o["strings"], o["shape"], 0.5, "point-based-std")
+    torch.cuda.synchronize()
+    free2 = torch.cuda.mem_get_info()[0]
+    assert free1 - free2 < 700 << 20, f"HBM grew by {(free1 - free2) >> 20} MB over 49 geometries (row-table cap is 512 MB)"
+    del net
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] >= free0, "destroying the codec must return its weights, workspace and row tables"

@@ -1,6 +1,7 @@
 """Pins the CPU oracle against fixtures produced by the REAL reference (tests/golden/make_golden.py):
 integer stages bit-exact; the ATen back-end reproduces every reference byte string; the
 numeric-contract ("cdet") back-end agrees with the reference to float rounding."""
+import functools
 import hashlib
 import json
 import os
@@ -195,3 +196,54 @@ def test_cust_map_torch_backend_equals_reference(idx):
     assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
     dec = orc.decompress(out["strings"], out["shape"], c["quality"], c["mask_pol"], cust_map=cm)["x_hat"].clamp(0, 1)
     assert hashlib.sha256(dec.numpy().tobytes()).hexdigest() == c["x_hat_sha"]
+
+
+# ------------------------------------------------------------------ multiple_encoder / force_enhanced
+def _multienc():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "multienc.json")))
+
+
+@functools.lru_cache(maxsize=None)
+def multienc_sd():
+    from progressivecodec_amd.arch import CodecConfig
+    from progressivecodec_amd.synth import synthetic_state_dict
+    sd = synthetic_state_dict(CodecConfig(multiple_encoder=True))
+    t = tables_npz()        # cc_* / h_* / entropy-model weights are those of the canonical synthetic model: the same tables apply
+    for p, k in (("gaussian_conditional", "gc"), ("entropy_bottleneck", "eb")):
+        sd[p + "._quantized_cdf"] = torch.from_numpy(t[k + "_cdf"])
+        sd[p + "._cdf_length"] = torch.from_numpy(t[k + "_len"])
+        sd[p + "._offset"] = torch.from_numpy(t[k + "_off"])
+    return sd
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_multiple_encoder_torch_backend_equals_reference(idx):
+    """multiple_encoder=True (CHProg_cnn.py:131-144,691-697): every byte string, mask popcount and the x_hat hash of the reference
+    (tests/golden/make_golden_multienc.py) are reproduced by the oracle's ATen back-end."""
+    c = _multienc()["multienc"][idx]
+    torch.set_num_threads(8)
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    orc = RefCodec(multienc_sd(), "torch")
+    out = orc.compress(x, c["quality"])
+    ys, zs = out["strings"]
+    assert [sha(s) for s in zs] == c["z_sha"]
+    assert [[sha(s) for s in sl] for sl in ys] == c["y_sha"]
+    assert [[int(m[b].sum()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    dec = orc.decompress(out["strings"], out["shape"], c["quality"])["x_hat"].clamp(0, 1)
+    assert sha(dec.numpy().tobytes()) == c["x_hat_sha"]
+
+
+@pytest.mark.parametrize("idx", [0, 1])
+def test_force_enhanced_torch_backend_equals_reference(idx):
+    """forward_single_quality(quality=0, force_enhanced=True) (CHProg_cnn.py:1006,1022,1064): likelihood subsample and x_hat hash
+    of the reference reproduced by the oracle's ATen back-end."""
+    c = _multienc()["forced"][idx]
+    torch.set_num_threads(8)
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    out = oracle_codec("torch").forward_single_quality(x, 0, force_enhanced=True)
+    ly = out["likelihoods"]["y"]
+    assert list(ly.shape) == c["y_shape"] and ly.shape[1] == 640
+    assert np.array_equal(ly.flatten()[::53].numpy(), np.asarray(c["y_sub"], np.float32))
+    assert abs(float(-torch.log2(ly.double()).sum()) - c["bits_y"]) <= 1e-9 * c["bits_y"]
+    assert sha(out["x_hat"].numpy().tobytes()) == c["x_hat_sha"]
+    assert all(int(m.sum()) == 0 for m in out["masks"])
