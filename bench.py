@@ -8,18 +8,25 @@ resident in HBM; the timed region covers device compute, entropy coding and prod
 host-visible byte strings (training/step.py:322-340 without file I/O).
 
   python bench.py --gpus N --steps K --warmup W
-N > 1: launched by torchrun, one rank per GPU; images shard per rank (weak scaling), no
-data-path collective; the only collective is the final gather of string lengths (outside
-the timed region) -- see DESIGN.md "multi-GPU".
+
+N ranks, one per GPU.  Under torchrun (RANK / WORLD_SIZE in the environment) this process IS one
+rank; started bare with --gpus N > 1 it launches the N ranks itself as child processes -- before
+anything touches the GPU -- and fails loudly if the node has fewer than N devices.  Images shard
+per rank (weak scaling: 32 images per GPU), weights replicate, there is no data-path collective;
+after the timed region the variable-length byte strings of every rank are gathered over RCCL
+(`parallel.gather_bitstreams`, two all-gathers over xGMI) and checked -- DESIGN.md "multi-GPU".
 
 Rank 0 prints ONE JSON line with `roofline` (the MFMA convolution kernel family, HIP-event
-timed, against the 157.3 TFLOP/s dense f32 matrix peak) and `cpu_baseline` (the CPU oracle
-port with ATen CPU ops, on a bounded sample of the same workload).
+timed, against the 157.3 TFLOP/s dense f32 matrix peak) and, at N = 1, `cpu_baseline` (the CPU
+oracle port with ATen CPU ops, on a bounded sample of the same workload, with its bpp / PSNR and
+the symbol-level differences between it and the GPU).
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +35,7 @@ sys.path.insert(0, ROOT)
 
 MFLOP_PER_PX_Q = 2.3251      # enc+dec, q > 0  (SURVEY.md section 8d / BASELINE.md section 3)
 PEAK_F32_MFMA = 157.3        # TFLOP/s, MI355X_MICROARCH.md "Peak FP32 (matrix)"
+MASK_POL = "point-based-std"
 
 
 def host_cores(cap=16):
@@ -43,6 +51,84 @@ def host_cores(cap=16):
     return max(1, min(n, cap))
 
 
+# ----------------------------------------------------------------------------- multi-rank plumbing (GPU-free: tests/test_parallel.py)
+def launch_ranks(n, argv):
+    """Start `n` ranks of this script as child processes (one per GPU) and relay rank 0's JSON line.  Runs BEFORE any GPU call of
+    this process (a process that has initialised the GPU must not exec / fork GPU workers).  Returns the exit code."""
+    import socket
+
+    import torch
+    have = torch.cuda.device_count()                        # (counting devices does not initialise the GPU)
+    if have < n:
+        print(f"[bench] --gpus {n} asked for, this node exposes {have} GPU(s): refusing to run a smaller job under that label "
+              f"(launch under torchrun on a node with {n} GPUs)", file=sys.stderr, flush=True)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def job_plan(world, rank, images_per_gpu):
+    """Weak scaling: the job is world * images_per_gpu images, rank r codes the contiguous shard parallel.shard_range gives it."""
+    from progressivecodec_amd.parallel import shard_range
+    total = world * images_per_gpu
+    b, e = shard_range(total, rank, world)
+    return total, b, e
+
+
+def final_gather(strings, world, rank, images_per_gpu, group=None, device=None):
+    """The job's only collective, after the timed region: every rank's y and z strings to every rank over the process group's
+    backend (nccl = RCCL over xGMI on the GPU box, gloo in the CPU tests); checks the gathered lists against this rank's own
+    strings and the plan.  Returns (total coded bytes of the job, number of images gathered)."""
+    from progressivecodec_amd.parallel import gather_bitstreams
+    y_strings, z_strings = strings
+    total, b, e = job_plan(world, rank, images_per_gpu)
+    all_y = gather_bitstreams(y_strings, group=group, device=device)
+    all_z = gather_bitstreams([z_strings], group=group, device=device)[0]
+    if len(all_z) != total or any(len(sl) != total for sl in all_y) or len(all_y) != len(y_strings):
+        raise RuntimeError(f"bitstream gather: expected {len(y_strings)} slices x {total} images, got {len(all_y)} x {[len(s) for s in all_y][:3]}...")
+    if all_z[b:e] != list(z_strings) or any(sl[b:e] != list(mine) for sl, mine in zip(all_y, y_strings)):
+        raise RuntimeError("bitstream gather: this rank's strings are not where the shard plan puts them")
+    return sum(len(s) for sl in all_y for s in sl) + sum(len(s) for s in all_z), total
+
+
+def source_hash():
+    """sha256 over the kernel / runtime sources: ties a profile under profiles/ to the build it was measured on (there is no .git
+    on the GPU box)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "progressivecodec_amd", "csrc", "*.h*")) + glob.glob(os.path.join(ROOT, "progressivecodec_amd", "csrc", "*.cpp")) +
+                    glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def newest_profile(pattern, src):
+    """newest profiles/<pattern> whose recorded source hash is this build's; (None, reason) otherwise"""
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    for f in reversed(cands):
+        try:
+            j = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if j.get("source_hash") == src:
+            return j, os.path.basename(f)
+    return None, (f"no profiles/{pattern} carries this build's source hash {src} (newest: {os.path.basename(cands[-1])})" if cands
+                  else f"no profiles/{pattern}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,10 +141,18 @@ def main():
     ap.add_argument("--cpu-images", type=int, default=32, help="images of rank 0's batch the CPU port codes (x2 repetitions)")
     args = ap.parse_args()
 
-    import torch
+    under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+    if not under_launcher and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): the two must agree", file=sys.stderr, flush=True)
+        sys.exit(2)
+    os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))    # one node: the host entropy-coding pool takes 1 / world of the CPUs, pinned
+
+    import torch
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -85,8 +179,8 @@ def main():
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
     def step():
-        out = net.compress(x, q, "point-based-std")
-        dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")
+        out = net.compress(x, q, MASK_POL)
+        dec = net.decompress(out["strings"], out["shape"], q, MASK_POL)
         return out, dec
 
     def barrier():
@@ -117,20 +211,23 @@ def main():
     # encode / decode split (informational; one extra step)
     torch.cuda.synchronize(dev)
     ta = time.perf_counter()
-    out = net.compress(x, q, "point-based-std")
+    out = net.compress(x, q, MASK_POL)
     torch.cuda.synchronize(dev)
     tb = time.perf_counter()
-    dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")
+    dec = net.decompress(out["strings"], out["shape"], q, MASK_POL)
     torch.cuda.synchronize(dev)
     tc = time.perf_counter()
 
     nbytes = sum(len(s) for sl in out["strings"][0] for s in sl) + sum(len(s) for s in out["strings"][1])
     bpp = 8.0 * nbytes / (B * S * S)
     psnr = -10.0 * torch.log10(torch.mean((x - dec["x_hat"]) ** 2)).item()
-    if world > 1:   # the final (tiny) gather: total coded bytes of the job
-        tt = torch.tensor([nbytes], device=dev, dtype=torch.int64)
-        dist.all_reduce(tt)
-        total_bytes = int(tt.item())
+    gather = None
+    if world > 1:   # the job's only collective: the variable-length strings of all ranks, over RCCL / xGMI, outside the timed region
+        tg = time.perf_counter()
+        total_bytes, n_img = final_gather(out["strings"], world, rank, B, device=dev)
+        torch.cuda.synchronize(dev)
+        gather = {"backend": "nccl (RCCL over xGMI)", "images": n_img, "bytes": total_bytes, "ms": round(1e3 * (time.perf_counter() - tg), 3),
+                  "checked": "every rank holds all strings; own shard in place"}
     else:
         total_bytes = nbytes
 
@@ -139,28 +236,33 @@ def main():
     h = net._h
     check(lib().pc_codec_profile_begin(h))
     step()
-    nl, ms, fl = C.c_int64(), C.c_double(), C.c_double()
+    nl, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
     check(lib().pc_codec_profile_end(h, C.byref(nl), C.byref(ms), C.byref(fl)))
+    check(lib().pc_codec_profile_bytes(h, C.byref(by)))
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
-    # HBM bytes per launch cannot be read inside this process: they come from the committed rocprofv3 PMC passes of this
-    # same command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/r*_hbm_traffic.json, folded by tools/pmc_traffic.py), or null
+    # HBM bytes per launch cannot be read inside this process: they come from the committed rocprofv3 PMC passes of this same command
+    # (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes; profiles/r*_hbm_traffic.json, folded by tools/pmc_traffic.py) -- and only
+    # from a file measured on THIS build (source hash), else null
+    src = source_hash()
     traffic, traffic_src = None, None
-    import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json")))      # newest round / letter last
-    tj = cands[-1] if cands else ""
-    if tj and B == 32 and S == 256:
-        fam = json.load(open(tj))["families"]
+    tj, why = newest_profile("r*_hbm_traffic.json", src)
+    if tj is not None and B == 32 and S == 256:
+        fam = tj["families"]
         n = sum(f["launches_per_2_steps"] for k, f in fam.items() if k.startswith("conv_igemm"))
         traffic = round(sum(f["launches_per_2_steps"] * f["hbm_bytes_per_launch"] for k, f in fam.items() if k.startswith("conv_igemm")) / n)
-        traffic_src = f"profiles/{os.path.basename(tj)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
+        traffic_src = f"profiles/{why} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on this build)"
+    else:
+        traffic_src = why if tj is None else "traffic profile is of the default workload only"
+    alg_bytes = by.value / max(1, nl.value)
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_uni_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": traffic, "traffic_unit": "HBM bytes per launch",
                 "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": None,
+                "algorithmic_bytes_per_launch": round(alg_bytes),
+                "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic else None,
                 "launches_per_step": int(nl.value), "kernel_ms_per_step": round(ms.value, 3),
                 "algorithmic_gflop_per_step": round(fl.value / 1e9, 2),
-                "avg_launch_us": round(1e3 * ms.value / max(1, nl.value), 2)}
+                "avg_launch_us": round(1e3 * ms.value / max(1, nl.value), 2), "source_hash": src}
 
     mp = world * B * S * S * args.steps / 1e6
     value = mp / elapsed
@@ -169,7 +271,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"Config 2: batch {B} x {S}x{S} random crops per GPU, quality {q}, mask_pol point-based-std, "
+        "config": {"workload": f"Config 2: batch {B} x {S}x{S} random crops per GPU, quality {q}, mask_pol {MASK_POL}, "
                                "synthetic seeded weights (canonical ChannelProgresssiveWACNN)",
                    "images_per_gpu": B, "height": S, "width": S, "quality": q, "sharding": f"images x {world} ranks"},
         "enc_ms": round(1e3 * (tb - ta), 2), "dec_ms": round(1e3 * (tc - tb), 2),
@@ -177,36 +279,81 @@ def main():
         "path_frac_of_f32_mfma_peak": round(value * 1e6 * MFLOP_PER_PX_Q * 1e6 / world / (PEAK_F32_MFMA * 1e12), 4),
         "roofline": roofline,
     }
+    if gather:
+        line["bitstream_gather"] = gather
+    # mask / entropy-prep stage: rocprofv3 kernel-trace durations of tools/stage_bench.py on a Config-4 slice (HBM-bound kernels)
+    sj, swhy = newest_profile("r*_stage_kernels_rocprof.json", src)
+    line["mask_entropy_stage"] = ({"source": f"profiles/{swhy}", **{k: v for k, v in sj.items() if k not in ("source_hash",)}} if sj is not None
+                                  else {"source": None, "why": swhy})
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (bench contract)
-        # CPU baseline: the oracle port (same ATen CPU op sequence as the reference, bit-identical strings on one
-        # machine -- tests/test_oracle_vs_golden.py), on a bounded sample of the same workload.
-        from oracle.codec_ref import RefCodec
-        log("cpu_baseline leg (oracle port, ATen CPU ops)")
-        cores = host_cores()
-        torch.set_num_threads(cores)
-        orc = RefCodec(sd, "torch")
-        orc.update()
-        n_img = max(1, args.cpu_images)
-        xc = x[:n_img].cpu()
-        reps = 2
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            for _ in range(reps):
-                o = orc.compress(xc, q)
-                d = orc.decompress(o["strings"], o["shape"], q)
-        dt = time.perf_counter() - t0
-        pairs = [(a[i], b[i]) for a, b in zip(out["strings"][0], o["strings"][0]) for i in range(n_img)]
-        same = sum(a == b for a, b in pairs)
-        line["cpu_baseline"] = {"value": round(reps * n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
-                                "sample": f"{n_img} of the {B} images of rank 0 ({S}x{S}, q={q}) as one batch, encode+decode x{reps}, "
-                                          f"torch {torch.__version__} CPU ops + C rANS, {dt:.1f} s",
-                                "y_strings_identical_to_gpu": f"{same}/{len(pairs)}"}
+        line["cpu_baseline"] = cpu_baseline_leg(net, sd, x, q, args, log)
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_leg(net, sd, x, q, args, log):
+    """CPU baseline: the oracle port (same ATen CPU op sequence as the reference; bit-identical strings with it on one machine --
+    tests/test_oracle_vs_golden.py), on a bounded sample of the same workload, plus what separates its output from the GPU's:
+    both encode the same images, so every difference is float rounding (oneDNN's summation order vs the contract's fmaf chain)
+    flipping a round() or a compare.  Reported: bpp / PSNR of both, the images with any flipped symbol, the slice where each first
+    diverges, the symbol / index mismatch rates overall and among the root slices."""
+    import numpy as np
+    import torch
+    from oracle.codec_ref import RefCodec
+    log("cpu_baseline leg (oracle port, ATen CPU ops)")
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    orc = RefCodec(sd, "torch")
+    orc.update()
+    S = x.shape[-1]
+    n_img = max(1, min(args.cpu_images, x.shape[0]))
+    xg = x[:n_img].contiguous()
+    xc = xg.cpu()
+    reps = 2
+    taps = {}
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for r in range(reps):
+            o = orc.compress(xc, q, taps=taps if r == 0 else None)
+            d = orc.decompress(o["strings"], o["shape"], q)
+    dt = time.perf_counter() - t0
+    g = net.compress(xg, q, MASK_POL)
+    HW = (S // 16) ** 2
+    gsym = net.read_tap("sym", np.int32)[: 20 * n_img * 32 * HW].reshape(20, n_img, 32 * HW)
+    gidx = net.read_tap("idx", np.int32)[: 20 * n_img * 32 * HW].reshape(20, n_img, 32 * HW)
+    gd = net.decompress(g["strings"], g["shape"], q, MASK_POL)["x_hat"].cpu()
+    csym = np.stack([taps[("b%d" % i) if i < 10 else ("e%d" % (i - 10))]["sym"].numpy().reshape(n_img, -1) for i in range(20)])
+    cidx = np.stack([taps[("b%d" % i) if i < 10 else ("e%d" % (i - 10))]["idx"].numpy().reshape(n_img, -1) for i in range(20)])
+    same = np.array([[a[b] == c[b] for b in range(n_img)] for a, c in zip(g["strings"][0], o["strings"][0])])    # [20][n_img]
+    first = [int(np.argmin(same[:, b])) if not same[:, b].all() else None for b in range(n_img)]
+    hist = {}
+    for f in first:
+        if f is not None:
+            hist[str(f)] = hist.get(str(f), 0) + 1
+    root_sym = sum(int((gsym[f, b] != csym[f, b]).sum()) for b, f in enumerate(first) if f is not None)
+    root_idx = sum(int((gidx[f, b] != cidx[f, b]).sum()) for b, f in enumerate(first) if f is not None)
+    nb = lambda st: sum(len(s) for sl in st[0] for s in sl) + sum(len(s) for s in st[1])
+    psnr = lambda a, b: -10.0 * torch.log10(torch.mean((a - b) ** 2)).item()
+    flip_free = [b for b, f in enumerate(first) if f is None]
+    d_ff = max((abs(psnr(xc[b], d["x_hat"][b]) - psnr(xc[b], gd[b])) for b in flip_free), default=None)
+    return {"value": round(reps * n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
+            "sample": f"{n_img} of the {x.shape[0]} images of rank 0 ({S}x{S}, q={q}) as one batch, encode+decode x{reps}, "
+                      f"torch {torch.__version__} CPU ops + C rANS, {dt:.1f} s",
+            "bpp": round(8.0 * nb(o["strings"]) / (n_img * S * S), 6), "psnr_db": round(psnr(xc, d["x_hat"]), 6),
+            "gpu_bpp_same_images": round(8.0 * nb(g["strings"]) / (n_img * S * S), 6), "gpu_psnr_db_same_images": round(psnr(xc, gd), 6),
+            "z_strings_identical_to_gpu": f"{sum(a == b for a, b in zip(g['strings'][1], o['strings'][1]))}/{n_img}",
+            "y_strings_identical_to_gpu": f"{int(same.sum())}/{same.size}",
+            "images_with_any_flip": f"{n_img - len(flip_free)}/{n_img}",
+            "first_diverging_slice_histogram": hist,
+            "symbol_mismatch_rate": float((gsym != csym).mean()), "index_mismatch_rate": float((gidx != cidx).mean()),
+            "root_flips": {"symbols": root_sym, "indexes": root_idx,
+                           "note": "differing elements inside each flipped image's FIRST diverging slice (the float-rounding flips themselves; "
+                                   "later slices differ because their context differs)"},
+            "max_abs_psnr_diff_db_flip_free_images": d_ff, "north_star_tolerance_db": 1e-4}
 
 
 if __name__ == "__main__":

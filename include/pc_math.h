@@ -21,6 +21,12 @@
 #ifndef PC_MATH_H
 #define PC_MATH_H
 
+/* Identifies the numeric contract a bitstream was coded under: high half = revision of the contraction order
+ * (2: aligned groups of 8 k visited 0,4,1,5,2,6,3,7, one fmaf chain per output element, bias added afterwards), low half = revision of
+ * the functions below.  A decoder built to another contract re-derives other mu / scale bits and desynchronises: containers carry
+ * this id and are refused on mismatch (progressivecodec_amd/container.py); pc_contract_id() exports it. */
+#define PC_NUMERIC_CONTRACT_ID 0x00020001u
+
 #include <math.h>
 #include <stdint.h>
 #include <string.h>

@@ -40,6 +40,11 @@ enum {
 };
 
 PC_API const char* pc_version(void);
+/* Id of the numeric contract this build codes under (include/pc_math.h: PC_NUMERIC_CONTRACT_ID).  Byte strings are only decodable by a
+ * build with the same id -- not by the reference's PyTorch path, nor by a build of another contract revision: the decoder re-derives
+ * mu / scale / mask from decoded data, and one differently rounded float desynchronises rANS.  No reference counterpart (the reference
+ * has no on-wire format and assumes encoder == decoder process). */
+PC_API uint32_t pc_contract_id(void);
 PC_API const char* pc_strerror(int code);
 PC_API int pc_last_hip_error(void);
 
@@ -233,6 +238,9 @@ PC_API int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W, do
  * event time and the algorithmic FLOPs (2*M*N*K per launch, no padding counted). */
 PC_API int pc_codec_profile_begin(pc_codec* c);
 PC_API int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_ms, double* total_flops);
+/* algorithmic HBM bytes (every operand of a launch once: input, weights, bias, output, aux tensors) summed over the launches recorded
+ * since pc_codec_profile_begin; read it after pc_codec_profile_end */
+PC_API int pc_codec_profile_bytes(const pc_codec* c, double* total_algorithmic_bytes);
 
 /* Debug/test taps: copy an internal device tensor of the last call to host ("y", "z", "latent_means", ...). */
 PC_API int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap_floats, size_t* n_floats);

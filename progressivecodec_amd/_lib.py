@@ -20,7 +20,7 @@ EXPORTS = [
     "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
     "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
-    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table",
+    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id",
 ]
 
 
@@ -45,6 +45,7 @@ def lib():
         L = C.CDLL(LIB_PATH)
         vp, i32p, f32p, u8p, sz = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float), C.POINTER(C.c_uint8), C.c_size_t
         L.pc_version.restype = C.c_char_p
+        L.pc_contract_id.restype = C.c_uint32
         L.pc_strerror.restype = C.c_char_p
         L.pc_strerror.argtypes = [C.c_int]
         L.pc_rans_bound.restype = sz
@@ -89,6 +90,7 @@ def lib():
         L.pc_codec_read_tap.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
         L.pc_codec_read_tap_i32.argtypes = [vp, C.c_char_p, vp, sz, C.POINTER(sz)]
         L.pc_codec_profile_begin.argtypes = [vp]
+        L.pc_codec_profile_bytes.argtypes = [vp, C.POINTER(C.c_double)]
         L.pc_codec_profile_end.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_double)]
         _lib = L
     return _lib

@@ -7,7 +7,8 @@ string and the ten base-slice strings are stored once, each level with quality >
 Layout (little endian):
 
     magic  "PCB1"                      4 B
-    version                            u8   (= 1)
+    version                            u8   (= 2)
+    numeric contract id                u32  (pc_contract_id() of the encoder: include/pc_math.h)
     mask policy                        u8   (1 point-based-std, 2 two-levels, 3 three-levels-std)
     n_levels                           u16
     H, W  (original, un-padded size)   u32 u32
@@ -21,11 +22,23 @@ Progressive property: the prefix ending with base slice 9 decodes level quality 
 other levels', so a reader wanting level l needs the header, the base segment and that level's segment only
 (`unpack(..., levels=[l])`).  The header costs 24 + 8*n_levels + 44 + 40*n_coded_levels bytes per image, which the reference's bpp
 (sum of string lengths) does not count; `payload_bytes()` returns the reference's figure.
+
+Interchange: the strings are decodable only by a decoder built to the SAME numeric contract -- the decoder
+re-derives mu / scale / mask from decoded data, so a build (or the reference's PyTorch path) that rounds one float differently
+desynchronises rANS and decodes garbage without any error.  The header therefore carries the encoder's contract id and `unpack`
+refuses a container of another contract (version-1 containers, which carry none, are refused as well).
 """
 import struct
 
 MAGIC = b"PCB1"
-VERSION = 1
+VERSION = 2
+_HEAD = "<BIBHIIHH"      # version, contract id, mask policy, n_levels, H, W, zh, zw
+
+
+def build_contract_id():
+    """pc_contract_id() of the loaded libpcodec.so"""
+    from ._lib import lib
+    return int(lib().pc_contract_id())
 MASK_POL = {"point-based-std": 1, "two-levels": 2, "three-levels-std": 3}
 _MASK_POL_INV = {v: k for k, v in MASK_POL.items()}
 
@@ -34,7 +47,7 @@ class ContainerError(ValueError):
     pass
 
 
-def pack(strings_per_level, shape, qualities, image_size, mask_pol="point-based-std", image_index=0):
+def pack(strings_per_level, shape, qualities, image_size, mask_pol="point-based-std", image_index=0, contract=None):
     """strings_per_level[l] = [y_strings, z_strings] as returned by compress()/compress_levels() for level l
     (y_strings[slice][image]); one container holds ONE image (image_index of the batch)."""
     qualities = [float(q) for q in qualities]
@@ -57,7 +70,8 @@ def pack(strings_per_level, shape, qualities, image_size, mask_pol="point-based-
                 raise ContainerError(f"level {q}: ten enhancement slices expected")
             enh.append([bytes(ys[s][b]) for s in range(10, 20)])
     H, W = int(image_size[0]), int(image_size[1])
-    head = MAGIC + struct.pack("<BBHIIHH", VERSION, MASK_POL[mask_pol], len(qualities), H, W, int(shape[0]), int(shape[1]))
+    contract = build_contract_id() if contract is None else int(contract)
+    head = MAGIC + struct.pack(_HEAD, VERSION, contract, MASK_POL[mask_pol], len(qualities), H, W, int(shape[0]), int(shape[1]))
     head += struct.pack(f"<{len(qualities)}d", *qualities)
     parts = [z] + base + [s for lv in enh for s in lv]
     if any(len(p) >= 1 << 32 for p in parts):
@@ -70,12 +84,15 @@ def parse_header(buf):
     """-> dict(mask_pol, qualities, image_size, shape, lengths (z, base[10], enh[level][10]), header_bytes)."""
     if len(buf) < 20 or buf[:4] != MAGIC:
         raise ContainerError("not a PCB1 container")
-    ver, mp, n_levels, H, W, zh, zw = struct.unpack_from("<BBHIIHH", buf, 4)
+    ver = buf[4]
     if ver != VERSION:
-        raise ContainerError(f"unsupported version {ver}")
+        raise ContainerError(f"unsupported version {ver}" + (" (version 1 carries no numeric-contract id: not decodable safely)" if ver == 1 else ""))
+    if len(buf) < 4 + struct.calcsize(_HEAD):
+        raise ContainerError("truncated header")
+    ver, contract, mp, n_levels, H, W, zh, zw = struct.unpack_from(_HEAD, buf, 4)
     if mp not in _MASK_POL_INV or n_levels == 0:
         raise ContainerError("corrupt header")
-    off = 4 + struct.calcsize("<BBHIIHH")
+    off = 4 + struct.calcsize(_HEAD)
     if len(buf) < off + 8 * n_levels:
         raise ContainerError("truncated header")
     qualities = list(struct.unpack_from(f"<{n_levels}d", buf, off))
@@ -86,16 +103,22 @@ def parse_header(buf):
         raise ContainerError("truncated header")
     lens = list(struct.unpack_from(f"<{n_parts}I", buf, off))
     off += 4 * n_parts
-    return {"mask_pol": _MASK_POL_INV[mp], "qualities": qualities, "image_size": (H, W), "shape": (zh, zw),
+    return {"contract": contract, "mask_pol": _MASK_POL_INV[mp], "qualities": qualities, "image_size": (H, W), "shape": (zh, zw),
             "z_len": lens[0], "base_lens": lens[1:11], "enh_lens": [lens[11 + 10 * i:21 + 10 * i] for i in range(n_coded)],
             "header_bytes": off}
 
 
-def unpack(buf, levels=None):
+def unpack(buf, levels=None, expect_contract=None):
     """-> (strings_per_level, shape, qualities, image_size, mask_pol) for the requested level indices (default: all), in the
     nesting compress() uses (y_strings[slice][image] with one image).  Only the bytes of the header, the base segment and the
-    requested levels' segments are touched, so a truncated file still yields the levels it holds completely."""
+    requested levels' segments are touched, so a truncated file still yields the levels it holds completely.  expect_contract: the
+    numeric-contract id the decoder implements (default: the loaded library's); a container of another contract is refused
+    (False: skip the check, e.g. to inspect lengths only)."""
     hd = parse_header(buf)
+    expect = build_contract_id() if expect_contract is None else expect_contract
+    if expect is not False and hd["contract"] != int(expect):
+        raise ContainerError(f"container was coded under numeric contract 0x{hd['contract']:08x}, this decoder implements 0x{int(expect):08x}: "
+                             "the streams are not interchangeable (DESIGN.md section 2)")
     qualities = hd["qualities"]
     want = list(range(len(qualities))) if levels is None else list(levels)
     off = hd["header_bytes"]

@@ -107,8 +107,8 @@ struct pc_codec {
     bool profile = false;
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
-    double prof_flops = 0.0;
-    struct ProfRec { int M, N, K, nphase, epi; double flops; };
+    double prof_flops = 0.0, prof_bytes = 0.0;
+    struct ProfRec { int M, N, K, nphase, epi; double flops, bytes; };
     std::vector<ProfRec> prof_rec;
     // slice-chain lanes: one pair of non-blocking streams per sub-batch
     struct Lane { hipStream_t sA = nullptr, sB = nullptr; hipEvent_t eA = nullptr, eB = nullptr, eDone = nullptr; };
@@ -151,9 +151,19 @@ int launch_conv(const pc_conv_params& q_in, hipStream_t st)
     }
     long taps = 0;
     for (int ph = 0; ph < q.nphase; ++ph) taps += q.ntap[ph];
-    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin * (q.ngroup == 2 ? 2.0 : 1.0);
+    const double ng = q.ngroup == 2 ? 2.0 : 1.0;
+    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin * ng;
+    // algorithmic HBM bytes of the launch (SURVEY.md section 8d style: every operand once): the input tensor once (all segments; a
+    // grouped launch reads a second first segment), the weights and bias of every phase / group, the output once, each aux tensor once
+    double by = 0.0;
+    for (int sg = 0; sg < q.nseg; ++sg) by += 4.0 * (double)q.B * q.H * q.W * q.seg[sg].nch * (sg == 0 ? ng : 1.0);
+    by += ng * 4.0 * ((double)taps * q.Cin * q.Cout + q.Cout);
+    by += ng * 4.0 * (double)q.nphase * q.M * q.Cout;
+    if (q.aux0 && q.epi != PC_EPI_NONE && q.epi != PC_EPI_GELU && q.epi != PC_EPI_CLAMP01) by += 4.0 * (double)q.nphase * q.M * q.Cout;
+    if (q.aux1 && (q.epi == PC_EPI_GATE || q.epi == PC_EPI_LRP_ADD)) by += 4.0 * (double)q.nphase * q.M * q.Cout;
     c->prof_flops += fl;
-    c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl});
+    c->prof_bytes += by;
+    c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl, by});
     HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
     const int r = pc_conv_launch(q, st);
     HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
@@ -1795,7 +1805,14 @@ extern "C" int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* hos
 extern "C" int pc_codec_profile_begin(pc_codec* c)
 {
     if (!c) return PC_ERR_ARG;
-    c->profile = true; c->ev_used = 0; c->prof_flops = 0.0; c->prof_rec.clear();
+    c->profile = true; c->ev_used = 0; c->prof_flops = 0.0; c->prof_bytes = 0.0; c->prof_rec.clear();
+    return PC_OK;
+}
+
+extern "C" int pc_codec_profile_bytes(const pc_codec* c, double* total_algorithmic_bytes)
+{
+    if (!c || !total_algorithmic_bytes) return PC_ERR_ARG;
+    *total_algorithmic_bytes = c->prof_bytes;                 // of the launches recorded since the last pc_codec_profile_begin
     return PC_OK;
 }
 
@@ -1812,12 +1829,12 @@ extern "C" int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* to
     }
     if (const char* path = std::getenv("PC_PROFILE_CSV")) {      // per-launch shapes and times, for tuning
         if (FILE* f = std::fopen(path, "w")) {
-            std::fprintf(f, "i,M,N,K,nphase,epi,gflop,us,tflops\n");
+            std::fprintf(f, "i,M,N,K,nphase,epi,gflop,us,tflops,alg_mbytes\n");
             for (size_t i = 0; i + 1 < c->ev_used && i / 2 < c->prof_rec.size(); i += 2) {
                 float t = 0.0f;
                 (void)hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
                 const auto& r = c->prof_rec[i / 2];
-                std::fprintf(f, "%zu,%d,%d,%d,%d,%d,%.3f,%.1f,%.2f\n", i / 2, r.M, r.N, r.K, r.nphase, r.epi, r.flops / 1e9, t * 1e3, r.flops / (t * 1e-3) / 1e12);
+                std::fprintf(f, "%zu,%d,%d,%d,%d,%d,%.3f,%.1f,%.2f,%.3f\n", i / 2, r.M, r.N, r.K, r.nphase, r.epi, r.flops / 1e9, t * 1e3, r.flops / (t * 1e-3) / 1e12, r.bytes / 1e6);
             }
             std::fclose(f);
         }

@@ -20,6 +20,7 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/pc_math.h"
 #include "../../include/pcodec.h"
 #include "pc_host.h"
 
@@ -390,7 +391,8 @@ extern "C" int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t*
     return rc;
 }
 
-extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.1 (gfx950)"; }
+extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.2 (gfx950), numeric contract 0x00020001"; }
+extern "C" uint32_t pc_contract_id(void) { return PC_NUMERIC_CONTRACT_ID; }
 
 extern "C" const char* pc_strerror(int code)
 {

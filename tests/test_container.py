@@ -25,7 +25,7 @@ def test_round_trip_all_and_selected_levels():
     out2, _, q2, _, _ = ct.unpack(buf, [2, 0])
     assert out2 == [lv[2], lv[0]] and q2 == [2, 0]
     hd = ct.parse_header(buf)
-    assert hd["header_bytes"] == 4 + 16 + 8 * 4 + 4 * (11 + 20)
+    assert hd["header_bytes"] == 4 + 20 + 8 * 4 + 4 * (11 + 20) and hd["contract"] == ct.build_contract_id()
     assert len(buf) == hd["header_bytes"] + hd["z_len"] + sum(hd["base_lens"]) + sum(map(sum, hd["enh_lens"]))
     for l in range(4):
         ys, zs = lv[l]
@@ -66,6 +66,15 @@ def test_errors():
         ct.parse_header(buf[:4] + bytes([9]) + buf[5:])            # unknown version
     with pytest.raises(ct.ContainerError):
         ct.parse_header(buf[:30])                                   # truncated header
+    with pytest.raises(ct.ContainerError) as ei:
+        ct.parse_header(buf[:4] + bytes([1]) + buf[5:])            # version 1: no contract id
+    assert "contract" in str(ei.value)
+    foreign = ct.pack(lv, (4, 6), q, (250, 380), contract=0x00010001)   # a stream coded under another contract revision
+    with pytest.raises(ct.ContainerError) as ei:
+        ct.unpack(foreign)
+    assert "not interchangeable" in str(ei.value)
+    assert ct.unpack(foreign, expect_contract=False)[0] == ct.unpack(buf)[0]          # inspection without the check
+    assert ct.unpack(foreign, expect_contract=0x00010001)[0] == ct.unpack(buf)[0]
     with pytest.raises(ct.ContainerError):
         ct.unpack(buf, [7])
     with pytest.raises(ct.ContainerError):

@@ -45,3 +45,49 @@ def test_gather_bitstreams_gloo_world2():
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
+
+
+# ------------------------------------------------------------------ bench.py's own multi-rank path
+def _bench_worker(rank, world, port, images_per_gpu):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    total, b, e = bench.job_plan(world, rank, images_per_gpu)
+    assert total == world * images_per_gpu and e - b == images_per_gpu and b == rank * images_per_gpu
+    # the strings a rank's compress() would return: 20 y slices x its images, then its z strings; content identifies (rank, slice, image)
+    ys = [[bytes([(rank * 31 + s * 7 + i) % 251]) * (8 + 4 * ((rank + s + i) % 9)) for i in range(images_per_gpu)] for s in range(20)]
+    zs = [bytes([200 + rank]) * (8 + 4 * (i % 3)) for i in range(images_per_gpu)]
+    nbytes, n_img = bench.final_gather([ys, zs], world, rank, images_per_gpu)
+    assert n_img == total
+    want = sum(8 + 4 * ((r + s + i) % 9) for r in range(world) for s in range(20) for i in range(images_per_gpu)) + \
+        sum(8 + 4 * (i % 3) for r in range(world) for i in range(images_per_gpu))
+    assert nbytes == want, (rank, nbytes, want)
+    dist.destroy_process_group()
+
+
+def test_bench_sharding_and_gather_at_world_size_8_gloo():
+    """bench.py's job plan (weak scaling, contiguous shards) and its final bitstream gather + checks, 8 ranks on CPU over gloo --
+    the code path the 8-GPU run takes after its timed region, with nccl in place of gloo."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_bench_worker, args=(8, port, 3), nprocs=8, join=True)
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` on a node with fewer than N GPUs must fail loudly, never report a smaller job as n_gpus = N."""
+    import subprocess
+    import sys
+    n_have = torch.cuda.device_count()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(max(2, n_have + 1)), "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "refusing" in r.stderr and "{" not in r.stdout
+    # under a launcher whose world size disagrees with --gpus it also refuses
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 2 and "must agree" in r.stderr

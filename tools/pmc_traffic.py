@@ -10,7 +10,9 @@ import json
 import os
 import sys
 
-FAMILIES = [("conv_igemm_dma_kernel", "conv_igemm_dma_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+FAMILIES = [("conv_igemm_uni_kernel", "conv_igemm_uni_kernel"), ("conv_igemm_dma_kernel", "conv_igemm_dma_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
             ("gc_prep", "gc_prep/dequant/eb"), ("gc_dequant", "gc_prep/dequant/eb"), ("eb_", "gc_prep/dequant/eb"),
             ("quantile", "quantile"), ("win_attention", "win_attention")]
 
@@ -45,7 +47,8 @@ def main():
         r = 2.0 * rd[k][1] * 1024.0 / n
         w = wr[k][1] * 1024.0 / max(1, wr[k][0])
         fam[k] = {"launches_per_2_steps": n, "hbm_read_bytes_per_launch": r, "hbm_write_bytes_per_launch": w, "hbm_bytes_per_launch": r + w}
-    print(json.dumps({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
+    from bench import source_hash
+    print(json.dumps({"source_hash": source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 bench.py --steps 1 --warmup 1 "
                                 "--no-cpu-baseline`, MI355X; FETCH_SIZE in KB doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
                                 "coalesced reads), WRITE_SIZE in KB as is; folded by tools/pmc_traffic.py", "families": fam}, indent=1))
 
