@@ -24,14 +24,16 @@ def main():
           if any(t in r["Kernel_Name"] for t in ("quantile", "gc_prep", "gc_dequant"))]
     n = B * 64 * 64 * 32
     stages = [("quantile threshold (layers/masking.py:218: torch.quantile per image)", "quantile", 4),
-              ("gc_prep_kernel<0> enhancement slice (mask + index + quantise + dequantise)", "gc_prep_kernelILi0", 36),
-              ("gc_prep_kernel<0> base slice", "gc_prep_kernelILi0", 24),
-              ("gc_prep_kernel<1> decoder index", "gc_prep_kernelILi1", 8),
+              ("gc_prep_kernel<0> enhancement slice (mask + index + quantise + dequantise)", "gc_prep_kernel<0>", 36),
+              ("gc_prep_kernel<0> base slice", "gc_prep_kernel<0>", 24),
+              ("gc_prep_kernel<1> decoder index", "gc_prep_kernel<1>", 8),
               ("gc_dequant_kernel", "gc_dequant", 12)]
     # calls in trace order
     calls, cur = [], None
     for name, ns in ks:
-        key = "quantile" if "quantile" in name else ("gc_prep_kernelILi0" if "gc_prep_kernelILi0" in name else ("gc_prep_kernelILi1" if "gc_prep_kernelILi1" in name else "gc_dequant"))
+        zero = "gc_prep_kernel<0>" in name or "gc_prep_kernelILi0" in name
+        one = "gc_prep_kernel<1>" in name or "gc_prep_kernelILi1" in name
+        key = "quantile" if "quantile" in name else ("gc_prep_kernel<0>" if zero else ("gc_prep_kernel<1>" if one else "gc_dequant"))
         if key == "quantile":
             if cur is None or cur[0] != "quantile" or "zero" in name or ("thr_kernel" in name):
                 cur = ["quantile", 0, 0]
