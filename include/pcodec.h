@@ -96,6 +96,15 @@ PC_API int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t* enc
                                 const int32_t* cdf_sizes, const int32_t* offsets,
                                 int32_t* symbols_out, int n_threads);
 
+/* The decoder's fast form of pc_rans_decode_batch: CDF indexes as bytes (n_cdf <= 256; the GaussianConditional has 64 rows), a per-row
+ * start table instead of the reference's linear scan (rans_interface.cpp:238-241), two streams per host thread in lock step.  Same
+ * symbols, same error codes. */
+PC_API int pc_rans_decode_batch_u8(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams,
+                                   const uint8_t* indexes, size_t n,
+                                   const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                   const int32_t* cdf_sizes, const int32_t* offsets,
+                                   int32_t* symbols_out, int n_threads);
+
 /* Replaces compressai._CXX.pmf_to_quantized_cdf (cpp_exts/ops/ops.cpp:10-67).  cdf_out has n+1 entries. */
 PC_API int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, uint32_t* cdf_out);
 

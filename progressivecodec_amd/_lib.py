@@ -20,7 +20,7 @@ EXPORTS = [
     "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
     "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
-    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id",
+    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id", "pc_rans_decode_batch_u8",
 ]
 
 
@@ -52,6 +52,7 @@ def lib():
         L.pc_rans_bound.argtypes = [sz]
         L.pc_rans_encode_with_indexes.argtypes = [vp, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp, sz, C.POINTER(sz)]
         L.pc_rans_decode_with_indexes.argtypes = [vp, sz, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp]
+        L.pc_rans_decode_batch_u8.argtypes = [vp, vp, sz, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int]
         L.pc_rans_decode_stream.argtypes = [vp, sz, vp, vp, sz, vp, C.c_int, C.c_int, vp, vp, vp]
         L.pc_host_pool_plan.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.pc_rans_encode_batch.argtypes = [vp, vp, sz, sz, vp, C.c_int, C.c_int, vp, vp, vp, sz, vp, C.c_int]

@@ -58,8 +58,10 @@ struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };   // d8: the
 
 struct Tables {
     std::vector<int32_t> cdf, len, off;
+    std::vector<uint16_t> lut;                   // decoder start table per row (pc_host.h: DecTables)
     int n = 0, stride = 0;
     bool ok() const { return n > 0; }
+    pc::DecTables dec() const { return pc::DecTables{cdf.data(), n, stride, len.data(), off.data(), lut.data()}; }
 };
 
 struct DevBuf { void* p = nullptr; size_t bytes = 0; };
@@ -759,14 +761,14 @@ extern "C" int pc_gc_prep_encode(const float* scale, int ld_scale, const float* 
 namespace {
 int prep_decode_index(const float* scale, int ld_scale, const float* thr, int mask_mode, int B, int HW, const float* scale_table,
                       int n_table, float scale_bound, int32_t* idx, float* mask, hipStream_t stream, const float* mask_src = nullptr,
-                      int64_t mask_sb = 0)
+                      int64_t mask_sb = 0, uint8_t* idx8 = nullptr)
 {
     if (!scale || !idx || !scale_table || (mask_mode == 1 && !thr)) return PC_ERR_ARG;
     pc_prep_params p;
     std::memset(&p, 0, sizeof(p));
     p.B = B; p.HW = HW; p.C = 32; p.scale = scale; p.ld_scale = ld_scale; p.thr = thr; p.mask_mode = mask_mode;
     p.table = scale_table; p.ntable = n_table; p.bound = scale_bound; p.idx = idx; p.mask = mask;
-    p.mask_src = mask_src; p.mask_sb = mask_sb;
+    p.mask_src = mask_src; p.mask_sb = mask_sb; p.idx8 = idx8;
     return pc_prep_dec_index_launch(p, stream);
 }
 }  // namespace
@@ -855,6 +857,8 @@ extern "C" int pc_codec_set_tables(pc_codec* c, int which, const int32_t* cdf, i
     t.len.assign(sizes, sizes + n_cdf);
     t.off.assign(offsets, offsets + n_cdf);
     t.n = n_cdf; t.stride = cdf_stride;
+    t.lut.assign((size_t)n_cdf * 256, 0);
+    pc::build_decode_lut(t.cdf.data(), t.n, t.stride, t.len.data(), t.lut.data());
     return PC_OK;
 }
 
@@ -1018,6 +1022,7 @@ struct ChainCtx {
     size_t M;                                   // B * HW
     float *y, *lm, *ls, *yb, *ye, *mu, *scale, *thr, *masks;
     int32_t *sym, *idx;
+    uint8_t* idx8;                              // decoder: byte copy of idx for the host coder
     int mode; float q; bool enh;
     int step0, step1;                           // chain steps to run: [0,10) base, [10,20) enhancement
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
@@ -1196,15 +1201,17 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
         const size_t so = (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
         const bool e = step >= NS0;
         const int i = e ? step - NS0 : step;
+        // the host coder reads the indexes back as bytes (a quarter of the int32 traffic on the per-slice critical path)
         PCCHK(prep_decode_index(k.scale + so, SLICE, e ? k.thr + (size_t)i * k.B + b0 : nullptr, e ? k.mode : 0, nb, k.HW,
                                 c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA,
-                                (e && k.cust_map) ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi));
-        HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
+                                (e && k.cust_map) ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi,
+                                k.idx8 + so));
+        uint8_t* h_idx8 = reinterpret_cast<uint8_t*>(h_idx);
+        HIPCHK(hipMemcpyAsync(h_idx8, k.idx8 + so, per * nb, hipMemcpyDeviceToHost, sA));
         HIPCHK(hipStreamSynchronize(sA));
         const auto td0 = std::chrono::steady_clock::now();
         const size_t slot = e ? (size_t)NS0 + (size_t)NS0 * k.level + i : (size_t)step;
-        PCCHK(pc_rans_decode_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx, per,
-                                   c->gc.cdf.data(), c->gc.n, c->gc.stride, c->gc.len.data(), c->gc.off.data(), h_sym, nt));   // :894,969
+        PCCHK(pc::rans_decode_u8_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx8, per, c->gc.dec(), h_sym, nt));   // :894,969
         { std::lock_guard<std::mutex> lk(c->buf_mu); c->t_host_decode_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); }
         HIPCHK(hipMemcpyAsync(k.sym + so, h_sym, per * nb * 4, hipMemcpyHostToDevice, sA));
         float* dst = e ? img(k.ye, b0, pi * D0) + 32 * i : img(k.yb, b0, pi * D0) + 32 * i;
@@ -1684,6 +1691,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     PCCHK(c->buf("thr", (size_t)B * NS0, &k.thr));
     PCCHK(c->buf("sym", M * SLICE * 2 * NS0, &k.sym));
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
+    PCCHK(c->buf("idx8", M * SLICE * 2 * NS0, &k.idx8));
     k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
     k.cust_map = c->cust_map; c->cust_map = nullptr;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;

@@ -101,6 +101,7 @@ struct pc_prep_params {
     const float* table; int ntable; float bound;
     int32_t* sym;                      // [B][C][HW]  (C,H,W raster order = rANS order)
     int32_t* idx;                      // [B][C][HW]
+    uint8_t* idx8;                     // optional (decoder): the same indexes as bytes, [B][C][HW] -- what the host coder reads back
     float* mask;                       // [B][C][HW] float 0/1 or null
     float* yhat; int ld_yhat;          // NHWC: float(sym) + mu
     float* lik; int64_t lik_sb;        // optional (encoder): Gaussian likelihood of the coded symbol, element (b, c, p) at

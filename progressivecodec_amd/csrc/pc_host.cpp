@@ -356,6 +356,93 @@ ThreadPool& default_pool()
 
 }  // namespace pc
 
+namespace pc {
+
+void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint16_t* lut)
+{
+    for (int r = 0; r < n; ++r) {
+        const int32_t* row = cdf + (size_t)r * stride;
+        int s = 0;
+        for (int hi = 0; hi < 256; ++hi) {
+            const int32_t v = hi << 8;
+            while (s + 1 < len[r] - 1 && row[s + 1] <= v) ++s;         // largest s <= len-2 with row[s] <= v
+            lut[(size_t)r * 256 + hi] = (uint16_t)s;
+        }
+    }
+}
+
+namespace {
+struct DecState {
+    const uint8_t* enc; size_t nw, p; uint64_t x; int err;
+    void init(const uint8_t* e, size_t len)
+    {
+        enc = e; nw = len / 4; p = 2; err = len < 8 ? PC_ERR_TRUNCATED : PC_OK; x = 0;
+        if (!err) { uint32_t w0, w1; std::memcpy(&w0, e, 4); std::memcpy(&w1, e + 4, 4); x = (uint64_t)w0 | ((uint64_t)w1 << 32); }
+    }
+    inline void renorm()
+    {
+        if (x < kRansL) {
+            if (p >= nw) { err = PC_ERR_TRUNCATED; return; }
+            uint32_t w; std::memcpy(&w, enc + 4 * p, 4); ++p;
+            x = (x << 32) | w;
+        }
+    }
+    inline int32_t bits() { const int32_t v = (int32_t)(x & ((1u << kBypassBits) - 1)); x >>= kBypassBits; renorm(); return v; }
+    inline int32_t symbol(int ci, const DecTables& t)
+    {
+        const int32_t len = t.len[ci];
+        const int32_t* cdf = t.cdf + (size_t)ci * t.stride;
+        const uint32_t cf = (uint32_t)(x & 0xFFFFu);
+        int32_t s = t.lut[(size_t)ci * 256 + (cf >> 8)];
+        while ((uint32_t)cdf[s + 1] <= cf) ++s;                           // cdf[len-1] = 65536 > cf: stops at s <= len-2
+        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)cdf[s + 1] - start;
+        x = (uint64_t)freq * (x >> kPrecision) + cf - start;
+        renorm();
+        int32_t value = s;
+        if (s == len - 2) {                                               // bypass, rans_interface.cpp:247-269
+            int32_t val = bits();
+            int32_t nb = val;
+            while (val == kBypassMax && !err) { val = bits(); nb += val; }
+            int32_t raw = 0;
+            for (int32_t j = 0; j < nb && !err; ++j) { val = bits(); if (j < 8) raw |= val << (j * kBypassBits); }
+            value = raw >> 1;
+            if (raw & 1) value = -value - 1; else value += len - 2;
+        }
+        return value + t.off[ci];
+    }
+};
+}  // namespace
+
+int rans_decode_u8_batch(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams, const uint8_t* indexes, size_t n,
+                         const DecTables& t, int32_t* out, int n_threads)
+{
+    if (!encoded || !encoded_lens || (!indexes && n) || !t.cdf || !t.lut || (!out && n)) return PC_ERR_ARG;
+    std::atomic<int> rc{PC_OK};
+    const size_t n_pairs = (n_streams + 1) / 2;
+    auto job = [&](size_t pr) {
+        const size_t a = 2 * pr, b = 2 * pr + 1 < n_streams ? 2 * pr + 1 : a;       // a lone last stream is paired with itself (decoded once)
+        DecState A, B;
+        A.init(encoded[a], encoded_lens[a]);
+        B.init(encoded[b], encoded_lens[b]);
+        const uint8_t *ia = indexes + a * n, *ib = indexes + b * n;
+        int32_t *oa = out + a * n, *ob = out + b * n;
+        if (A.err || B.err) { rc = PC_ERR_TRUNCATED; return; }
+        const bool two = b != a;
+        for (size_t i = 0; i < n; ++i) {
+            const int ca = ia[i], cb = ib[i];
+            if (ca >= t.n || cb >= t.n) { rc = PC_ERR_INDEX; return; }
+            oa[i] = A.symbol(ca, t);
+            if (two) ob[i] = B.symbol(cb, t);
+            if (A.err | B.err) { rc = PC_ERR_TRUNCATED; return; }
+        }
+    };
+    if (n_threads == 1) for (size_t j = 0; j < n_pairs; ++j) job(j);
+    else default_pool().parallel_for(n_pairs, job);
+    return rc;
+}
+
+}  // namespace pc
+
 extern "C" int pc_rans_encode_batch(const int32_t* symbols, const int32_t* indexes, size_t n_streams, size_t n,
                                     const int32_t* cdfs, int n_cdf, int cdf_stride,
                                     const int32_t* cdf_sizes, const int32_t* offsets,
@@ -389,6 +476,24 @@ extern "C" int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t*
     if (n_threads == 1) for (size_t s = 0; s < n_streams; ++s) job(s);
     else pc::default_pool().parallel_for(n_streams, job);
     return rc;
+}
+
+extern "C" int pc_rans_decode_batch_u8(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams,
+                                       const uint8_t* indexes, size_t n,
+                                       const int32_t* cdfs, int n_cdf, int cdf_stride,
+                                       const int32_t* cdf_sizes, const int32_t* offsets,
+                                       int32_t* out, int n_threads)
+{
+    if (!cdfs || !cdf_sizes || !offsets || n_cdf <= 0 || n_cdf > 256 || cdf_stride < 2) return PC_ERR_ARG;
+    for (int i = 0; i < n_cdf; ++i) {                                // the start table needs well-formed rows (rans_interface.cpp:48-57)
+        const int32_t* row = cdfs + (size_t)i * cdf_stride;
+        if (cdf_sizes[i] < 2 || cdf_sizes[i] > cdf_stride || row[0] != 0 || row[cdf_sizes[i] - 1] != (1 << 16)) return PC_ERR_CDF;
+        for (int j = 0; j + 1 < cdf_sizes[i]; ++j) if (row[j + 1] <= row[j]) return PC_ERR_CDF;
+    }
+    std::vector<uint16_t> lut((size_t)n_cdf * 256);
+    pc::build_decode_lut(cdfs, n_cdf, cdf_stride, cdf_sizes, lut.data());
+    return pc::rans_decode_u8_batch(encoded, encoded_lens, n_streams, indexes, n, pc::DecTables{cdfs, n_cdf, cdf_stride, cdf_sizes, offsets, lut.data()}, out,
+                                    n_threads);
 }
 
 extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.2 (gfx950), numeric contract 0x00020001"; }

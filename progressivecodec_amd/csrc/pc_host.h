@@ -2,6 +2,7 @@
 #ifndef PC_HOST_H
 #define PC_HOST_H
 #include <cstddef>
+#include <cstdint>
 #include <functional>
 
 namespace pc {
@@ -17,5 +18,16 @@ private:
     int n_;
 };
 ThreadPool& default_pool();
+
+// The decoder's fast path (pc_codec.hip): byte indexes (the device packs them: four times less D2H traffic per slice), a 256-entry
+// start table per CDF row instead of a binary search, and two streams decoded in lock step by one thread (two independent rANS
+// states give the core something to overlap the dependent loads of one with).  Same symbols as pc_rans_decode_with_indexes.
+struct DecTables {
+    const int32_t* cdf; int n, stride; const int32_t* len; const int32_t* off;
+    const uint16_t* lut;          // [n][256]: largest s with cdf[s] <= (hi << 8), built by build_decode_lut
+};
+void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint16_t* lut);
+int rans_decode_u8_batch(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams, const uint8_t* indexes, size_t n,
+                         const DecTables& t, int32_t* out, int n_threads);
 }  // namespace pc
 #endif

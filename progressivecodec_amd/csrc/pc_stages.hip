@@ -464,6 +464,7 @@ __global__ __launch_bounds__(256) void gc_prep_kernel(const pc_prep_params p)
         if (p0 + px >= p.HW) continue;
         const int64_t o = ((int64_t)b * CC + c) * p.HW + p0 + px;
         p.idx[o] = t_idx[c][px];
+        if (p.idx8) p.idx8[o] = (uint8_t)t_idx[c][px];
         if (MODE == 0) p.sym[o] = t_sym[c][px];
         if (p.mask) p.mask[o] = t_msk[c][px];
         if (MODE == 0 && p.lik) p.lik[(int64_t)b * p.lik_sb + (int64_t)c * p.HW + p0 + px] = t_lik[c][px];

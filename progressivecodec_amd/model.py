@@ -67,7 +67,7 @@ class ChannelProgresssiveWACNN(_module_base()):
         h = self.__dict__.get("_h", None)
         if h is not None and h.value:
             lib().pc_codec_destroy(h)
-            self._h = C.c_void_p()
+            self.__dict__["_h"] = C.c_void_p()
 
     # ------------------------------------------------------------------ nn.Module surface
     def to(self, *args, **kwargs):

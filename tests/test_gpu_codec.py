@@ -655,3 +655,32 @@ def test_row_table_cache_is_bounded_and_freed():
     gc.collect()
     torch.cuda.synchronize()
     assert torch.cuda.mem_get_info()[0] >= free0, "destroying the codec must return its weights, workspace and row tables"
+
+
+def test_config4_per_gpu_shard_32x1024x1024():
+    """BASELINE Config 4's per-GPU shard at FULL size: 32 tiles of 1024x1024 in one call (the "~45 GB of workspace" case of DESIGN.md
+    section 3; int32 pixel indices, 64-bit offsets, the multi-block quantile and the 2 GB-class buffers are all exercised).  Too large
+    for the oracle, so size-independent properties: an image codes identically inside the batch and alone, the decoder reproduces
+    the single-image reconstruction, masks hold the requested share, HBM use is reported."""
+    net = gpu_codec()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    g = torch.Generator().manual_seed(1000)
+    x = torch.rand(32, 3, 1024, 1024, generator=g).cuda()
+    q = 0.5
+    out = net.compress(x, q, "point-based-std")
+    torch.cuda.synchronize()
+    used = (free0 - torch.cuda.mem_get_info()[0]) / 2 ** 30
+    print(f"Config 4 shard (32 x 1024^2): {used:.1f} GiB of HBM beyond the weights (input batch 0.4 GiB included)")
+    assert used < 120.0
+    one = net.compress(x[17:18].contiguous(), q, "point-based-std")
+    assert [sl[17] for sl in out["strings"][0]] == [sl[0] for sl in one["strings"][0]] and out["strings"][1][17] == one["strings"][1][0]
+    k = 32 * 64 * 64
+    for m in out["masks"]:
+        s = m.sum(dim=(1, 2, 3)).cpu()
+        assert ((s - 0.05 * k).abs() <= 4).all(), s
+    dec = net.decompress(out["strings"], out["shape"], q, "point-based-std")["x_hat"]
+    dec1 = net.decompress(one["strings"], one["shape"], q, "point-based-std")["x_hat"]
+    assert torch.equal(dec[17], dec1[0]) and 0.0 <= dec.min().item() and dec.max().item() <= 1.0
+    bpp = bpp_of(out["strings"], 32, 1024, 1024)
+    assert 1.0 < bpp < 10.0

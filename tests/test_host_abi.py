@@ -75,6 +75,16 @@ def test_rans_matches_oracle_on_random_streams_and_batches():
     dec = np.zeros((n_streams, n), np.int32)
     assert L.pc_rans_decode_batch(ptrs, ln, n_streams, P(idx), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec), 0) == 0
     assert np.array_equal(dec, sym)
+    # the decoder's fast form (byte indexes, start table, two streams per thread; odd stream count: the last one is alone)
+    idx8 = idx.astype(np.uint8)
+    for nt in (0, 1):
+        dec8 = np.zeros((n_streams, n), np.int32)
+        assert L.pc_rans_decode_batch_u8(ptrs, ln, n_streams, P(idx8), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec8), nt) == 0
+        assert np.array_equal(dec8, sym)
+    short = (C.c_size_t * n_streams)(*[len(e) // 2 // 4 * 4 for e in enc])
+    assert L.pc_rans_decode_batch_u8(ptrs, short, n_streams, P(idx8), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec8), 0) == -4
+    bad = idx8.copy(); bad[3, 5] = 64
+    assert L.pc_rans_decode_batch_u8(ptrs, ln, n_streams, P(bad), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec8), 0) == -2
 
 
 def test_rans_edge_cases_and_errors():
