@@ -195,6 +195,13 @@ PC_API int pc_codec_compress(pc_codec* c, const float* x, int B, int H, int W, d
  * (top quality*10 % per image and slice; quality >= 10 all, 0 none, whatever the mask policy) instead of the scale, then the
  * pointer is cleared.  NULL clears it. */
 PC_API int pc_codec_set_cust_map(pc_codec* c, const float* cust_map);
+/* The REM model family -- PostRateProcessedNetwork (models/CHProgREM.py:205; compress :673, decompress :896): a frozen base codec whose
+ * predicted scale of every enhancement slice is refined by a LatentRateReduction CNN (:12-86, apply_latent_enhancement :375-428) chosen
+ * by the range [check_levels[k], check_levels[k+1]) the quality falls in.  The CNN weights are state-dict tensors named
+ * "post_latent.<level>.<slice>.<subnet>.<block>.{conv1,conv2,skip}.{weight,bias}" set with pc_codec_set_tensor before
+ * pc_codec_finalize.  n_levels in 1..3 switches the refinement on for the following compress / decompress / forward calls (mu_std =
+ * False, no checkpoint_rep), 0 switches it off (plain ChannelProgresssiveWACNN). */
+PC_API int pc_codec_set_rem(pc_codec* c, const double* check_levels, int n_levels);
 PC_API int pc_codec_num_slices(const pc_codec* c);
 /* string of y slice `slice` (0..n_slices-1) or of z (slice = -1) for image b */
 PC_API int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len);

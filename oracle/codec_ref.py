@@ -50,6 +50,9 @@ class TorchOps:
     def sigmoid(self, x):
         return torch.sigmoid(x)
 
+    def leaky(self, x):                             # nn.LeakyReLU() default slope (models/utils.py:65)
+        return F.leaky_relu(x, 0.01)
+
     def gdn(self, x, beta, gamma, inverse):         # layers/gdn.py:50-63
         C = x.shape[1]
         norm = F.conv2d(x ** 2, gamma.reshape(C, C, 1, 1), beta)
@@ -146,6 +149,10 @@ class CDetOps:
 
     def sigmoid(self, x):
         return torch.from_numpy(lo.unary(x.numpy(), "sigmoid"))
+
+    def leaky(self, x):                             # x > 0 ? x : x * float32(0.01): one correctly rounded multiply, same on every device
+        a = x.numpy()
+        return torch.from_numpy(np.where(a > 0, a, a * np.float32(0.01)).astype(np.float32))
 
     def gdn(self, x, beta, gamma, inverse):
         B, C, H, W = x.shape
@@ -374,6 +381,10 @@ class RefCodec:
         return [base[i]] + (enh[i - min(MAX_SUPPORT, i):i] if i > 0 else [])
 
     # ---- compress / decompress
+    def refine_scale(self, i, quality, mask_pol, y_b_hat, mu_base, std_base, mu, scale):
+        """hook of the REM model (RemCodec below): the plain codec leaves the predicted scale alone"""
+        return scale
+
     def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None, cust_map=None, force_enhanced=False):
         """ChannelProgresssiveWACNN.compress, models/CHProg_cnn.py:686-847.  force_enhanced (forward_single_quality only,
         :1006,1022,1064): at quality 0 still run both hyper-priors and the enhancement chain (all-zero masks)."""
@@ -414,6 +425,7 @@ class RefCodec:
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
+            scale = self.refine_scale(i, quality, mask_pol, base[i], T[f"b{i}"]["mu"], T[f"b{i}"]["scale"], mu, scale)
             mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :819-824
             masks.append(mask)
             idx = self._indexes(scale * mask)                               # :828
@@ -494,13 +506,14 @@ class RefCodec:
         z_sym = self._decode(z_strings, self._eb_indexes(B, zh, zw), self.eb)       # :855
         z_hat = z_sym.float() + med
         lm, ls = self._hyper(z_hat, quality)
-        base = []
+        base, mu_b, std_b = [], [], []
         for i in range(NS0):                                                # :874-904
             sup = base[:min(MAX_SUPPORT, i)]
             mean_support = torch.cat([lm[:, :D0]] + sup, 1)
             scale_support = torch.cat([ls[:, :D0]] + sup, 1)
             mu = self.stack5("cc_mean_transforms", i, mean_support)
             scale = self.stack5("cc_scale_transforms", i, scale_support)
+            mu_b.append(mu); std_b.append(scale)
             idx = self._indexes(scale)
             sym = self._decode(y_strings[i], idx, self.gc)                  # :894
             y_hat = sym.float() + mu                                        # :896
@@ -517,6 +530,7 @@ class RefCodec:
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
+            scale = self.refine_scale(i, quality, mask_pol, base[i], mu_b[i], std_b[i], mu, scale)
             mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :960-965
             idx = self._indexes(scale * mask)                               # :968
             sym = self._decode(y_strings[NS0 + i], idx, self.gc)
@@ -526,6 +540,68 @@ class RefCodec:
         y_hat = torch.cat(enh, 1)
         T.update(y_hat=y_hat)
         return {"x_hat": self.g_s(1, y_hat).clamp_(0, 1)}                   # :986-990
+
+
+# ----------------------------------------------------------------------------- REM (models/CHProgREM.py)
+class RemCodec(RefCodec):
+    """PostRateProcessedNetwork.compress / .decompress (models/CHProgREM.py:673-888, :896-1126) for mu_std=False, escalation=False,
+    checkpoint_rep=None, real_compress=True: the base codec's chain, with the predicted scale of every enhancement slice refined by a
+    LatentRateReduction CNN (:12-86) before the mask is taken -- apply_latent_enhancement (:375-428).  `post_sd`: the state dict of
+    `post_latent` ("<level>.<slice>.<subnet>.<block>.conv1.weight" ...)."""
+
+    def __init__(self, state_dict, post_sd, backend="torch", check_levels=(0.01, 0.25, 1.75), **kw):
+        super().__init__(state_dict, backend, **kw)
+        self.post = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in post_sd.items()}
+        self.check_levels = list(check_levels)
+
+    def _rb(self, x, p):                                # ResidualBlock, models/utils.py:59-87
+        w1, b1, w2, b2 = (self.post[f"{p}.{n}"] for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"))
+        out = self.ops.leaky(self.ops.conv(x, w1, b1, 1, 1))
+        out = self.ops.leaky(self.ops.conv(out, w2, b2, 1, 1))
+        ident = x
+        if f"{p}.skip.weight" in self.post:
+            ident = self.ops.conv(x, self.post[f"{p}.skip.weight"], self.post[f"{p}.skip.bias"], 1, 0)
+        return out + ident
+
+    def _seq(self, x, p):
+        j = 0
+        while f"{p}.{j}.conv1.weight" in self.post:
+            x = self._rb(x, f"{p}.{j}")
+            j += 1
+        return x
+
+    def find_check_quality(self, quality):              # :446-466
+        c = self.check_levels
+        if quality <= c[0]:
+            return 0, 0
+        if len(c) in (2, 3) and c[0] < quality <= c[1]:
+            return c[0], c[1]
+        if len(c) == 2 and quality > c[1]:
+            return c[1], 10
+        if len(c) == 3 and c[1] < quality <= c[2]:
+            return c[1], c[-1]
+        return c[-1], 10
+
+    def refine_scale(self, i, quality, mask_pol, y_b_hat, mu_base, std_base, mu, scale):
+        """apply_latent_enhancement, :375-428 (attention mask = star - bar from the UNREFINED scale, rounded; nothing below the first
+        check level; the net of the quality's range), then LatentRateReduction.forward :74-86."""
+        c = self.check_levels
+        if quality <= c[0]:
+            return scale
+        q_bar, _ = self.find_check_quality(quality)
+        att = torch.round(self._mask(scale, quality, mask_pol) - self._mask(scale, q_bar, mask_pol))
+        if len(c) == 1:
+            k = 0
+        elif len(c) == 2:
+            k = 0 if c[0] < quality <= c[1] else 1
+        else:
+            k = 0 if c[0] < quality <= c[1] else (1 if c[1] < quality <= c[2] else 2)
+        p = f"{k}.{i}"
+        f_ent_prog = self._seq(scale, p + ".enc_enh_entropy_params")
+        f_latent = self._seq(y_b_hat, p + ".enc_base_rep")
+        f_ent_base = self._seq(torch.cat([mu_base, std_base], 1), p + ".enc_base_entropy_params")
+        ret = self._seq(torch.cat([f_latent, f_ent_base, f_ent_prog], 1), p + ".enc")
+        return ret * att + scale
 
 
 # ----------------------------------------------------------------------------- harness (training/step.py:277-404)

@@ -20,7 +20,7 @@ EXPORTS = [
     "pc_codec_num_slices", "pc_codec_get_string", "pc_codec_decompress", "pc_codec_read_tap", "pc_codec_read_tap_i32",
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
     "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
-    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id", "pc_rans_decode_batch_u8",
+    "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id", "pc_rans_decode_batch_u8", "pc_codec_set_rem",
 ]
 
 
@@ -83,6 +83,7 @@ def lib():
         L.pc_codec_get_level_string.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]
         L.pc_codec_decompress_levels.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.pc_codec_set_cust_map.argtypes = [vp, vp]
+        L.pc_codec_set_rem.argtypes = [vp, vp, C.c_int]
         L.pc_codec_strings_size.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int)]
         L.pc_codec_copy_strings.argtypes = [vp, vp, sz, vp, sz]
         L.pc_codec_decompress_packed.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]

@@ -193,3 +193,35 @@ def param_spec(cfg: CodecConfig = CodecConfig()) -> "OrderedDict[str, tuple]":
         for i in range(cfg.ns0):
             _stack5(s, f"{fam}.{i}", cc_in_channels(cfg, fam, i))
     return s
+
+
+# ----------------------------------------------------------------------------- REM (rate-enhancement module)
+REM_SUBNETS = ("enc_base_entropy_params", "enc_enh_entropy_params", "enc_base_rep", "enc")
+
+
+def rem_subnet_blocks(dimension="big", N=32):
+    """(in, out) channels of the ResidualBlocks of one LatentRateReduction (reference models/CHProgREM.py:12-72, mu_std=False)."""
+    extra = [(N, N)] if dimension == "big" else []
+    return {
+        "enc_base_entropy_params": [(2 * N, N), (N, N)] + extra,
+        "enc_enh_entropy_params": [(N, N), (N, N)] + extra,
+        "enc_base_rep": [(N, N), (N, N)] + extra,
+        "enc": [(3 * N, 2 * N), (2 * N, 2 * N)] + ([(2 * N, 2 * N)] if dimension == "big" else []) + [(2 * N, N)],
+    }
+
+
+def rem_param_spec(check_multiple=3, dimension="big", N=32) -> "OrderedDict[str, tuple]":
+    """State-dict layout of PostRateProcessedNetwork.post_latent (CHProgREM.py:227-234): [check level][slice] LatentRateReduction,
+    each ResidualBlock = conv1 3x3, conv2 3x3 and, when in != out, a 1x1 skip (models/utils.py:59-87).  name -> (shape, dtype, kind)."""
+    s = OrderedDict()
+    blocks = rem_subnet_blocks(dimension, N)
+    for k in range(check_multiple):
+        for i in range(10):
+            for sub in REM_SUBNETS:
+                for j, (ci, co) in enumerate(blocks[sub]):
+                    p = f"{k}.{i}.{sub}.{j}"
+                    _conv(s, p + ".conv1", ci, co, 3)
+                    _conv(s, p + ".conv2", co, co, 3)
+                    if ci != co:
+                        _conv(s, p + ".skip", ci, co, 1)
+    return s

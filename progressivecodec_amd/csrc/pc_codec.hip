@@ -53,6 +53,8 @@ struct GdnW { float* beta = nullptr; float* gamma = nullptr; int C = 0; };   // 
 struct RuW { ConvW c0, c2, c4; };
 struct WamW { RuW a[3], b[3]; ConvW qkv, proj, out; float* bias = nullptr; int C = 0, ws = 0, shift = 0; };
 struct Stack5W { ConvW c[5]; };
+struct RbW { ConvW c1, c2, skip; bool has_skip = false; };                        // ResidualBlock (models/utils.py:59-87)
+struct LrrW { RbW ent_base[3], ent_enh[3], base_rep[3], enc[4]; int n_sub = 0, n_enc = 0; };   // LatentRateReduction (CHProgREM.py:12-72)
 struct HsW { ConvW c0, c2, c4, c6, c8; };
 struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };   // d8: the 192 -> 3 deconv in sub-pixel form (load_deconv3_subpixel)
 
@@ -78,6 +80,11 @@ struct pc_codec {
     // network
     struct GaW { ConvW c0, c2, c5, c7; GdnW g1, g3, g6; WamW w4, w8; };
     GaW ga[2];                                   // ga[1] only with multiple_encoder (CHProg_cnn.py:131-144)
+    // REM: PostRateProcessedNetwork.post_latent[level][slice] (CHProgREM.py:227-234), loaded when the state dict carries post_latent.* keys
+    std::vector<LrrW> rem;                       // [level * NS0 + slice]
+    int rem_levels_loaded = 0;                   // check levels with weights
+    int rem_n = 0;                               // active check levels (0: REM off) -- pc_codec_set_rem
+    double rem_check[3] = {0, 0, 0};
     bool multi_enc = false;                      // two 3 -> 320 encoders, y = cat(g_a[0](x), g_a[1](x))  (:691-697)
     GsW gs[2];
     ConvW ha[5];
@@ -304,6 +311,15 @@ int load_wam(pc_codec* c, const std::string& p, int C, int ws, int shift, WamW* 
             for (int h = 0; h < HEADS; ++h) dense[((size_t)h * T + i) * T + j] = t[r * HEADS + h];
         }
     PCCHK(upload(c, dense, &w->bias));
+    return PC_OK;
+}
+
+int load_rb(pc_codec* c, const std::string& p, int ci, int co, RbW* r)
+{
+    PCCHK(load_conv(c, p + ".conv1", ci, co, 3, 0, &r->c1));
+    PCCHK(load_conv(c, p + ".conv2", co, co, 3, 0, &r->c2));
+    r->has_skip = ci != co;
+    if (r->has_skip) PCCHK(load_conv(c, p + ".skip", ci, co, 1, 0, &r->skip));
     return PC_OK;
 }
 
@@ -951,6 +967,30 @@ extern "C" int pc_codec_finalize(pc_codec* c)
         if (!b) return PC_ERR_MISSING;
         c->scale_bound = reinterpret_cast<const float*>(b->data.data())[0];
     }
+    {   // REM weights, if the caller set them (keys post_latent.<level>.<slice>.<subnet>.<block>...): 2 or 3 blocks per sub-net
+        // ("middle" / "big"), enc one more
+        int levels = 0;
+        while (levels < 3 && c->sd.count("post_latent." + std::to_string(levels) + ".0.enc.0.conv1.weight")) ++levels;
+        if (levels) {
+            const int n_sub = c->sd.count("post_latent.0.0.enc_base_rep.2.conv1.weight") ? 3 : 2;
+            c->rem.assign((size_t)levels * NS0, LrrW{});
+            for (int k = 0; k < levels; ++k)
+                for (int i = 0; i < NS0; ++i) {
+                    LrrW& L = c->rem[(size_t)k * NS0 + i];
+                    L.n_sub = n_sub; L.n_enc = n_sub + 1;
+                    const std::string p = "post_latent." + std::to_string(k) + "." + std::to_string(i) + ".";
+                    for (int j = 0; j < n_sub; ++j) {
+                        const std::string js = "." + std::to_string(j);
+                        PCCHK(load_rb(c, p + "enc_base_entropy_params" + js, j == 0 ? 2 * SLICE : SLICE, SLICE, &L.ent_base[j]));
+                        PCCHK(load_rb(c, p + "enc_enh_entropy_params" + js, SLICE, SLICE, &L.ent_enh[j]));
+                        PCCHK(load_rb(c, p + "enc_base_rep" + js, SLICE, SLICE, &L.base_rep[j]));
+                    }
+                    for (int j = 0; j < L.n_enc; ++j)
+                        PCCHK(load_rb(c, p + "enc." + std::to_string(j), j == 0 ? 3 * SLICE : 2 * SLICE, j == L.n_enc - 1 ? SLICE : 2 * SLICE, &L.enc[j]));
+                }
+            c->rem_levels_loaded = levels;
+        }
+    }
     c->sd.clear();
     c->finalized = true;
     return PC_OK;
@@ -969,6 +1009,18 @@ extern "C" int pc_codec_set_scale_table(pc_codec* c, const float* table, int n)
     float* dev = nullptr;
     PCCHK(upload(c, t, &dev));
     c->scale_table = dev; c->n_table = n;
+    return PC_OK;
+}
+
+extern "C" int pc_codec_set_rem(pc_codec* c, const double* check_levels, int n_levels)
+{
+    // PostRateProcessedNetwork(base_net, check_levels) (CHProgREM.py:207-235): from now on compress / decompress refine the predicted
+    // scale of every enhancement slice with the LatentRateReduction net of the quality's range; n_levels = 0 switches it off again
+    if (!c || n_levels < 0 || n_levels > 3 || (n_levels && !check_levels)) return PC_ERR_ARG;
+    if (n_levels && (!c->finalized || c->rem_levels_loaded < n_levels)) return PC_ERR_STATE;
+    for (int i = 0; i + 1 < n_levels; ++i) if (!(check_levels[i] < check_levels[i + 1])) return PC_ERR_ARG;
+    c->rem_n = n_levels;
+    for (int i = 0; i < n_levels; ++i) c->rem_check[i] = check_levels[i];
     return PC_OK;
 }
 
@@ -1024,6 +1076,7 @@ struct ChainCtx {
     int32_t *sym, *idx;
     uint8_t* idx8;                              // decoder: byte copy of idx for the host coder
     int mode; float q; bool enh;
+    double quality; int mask_pol;               // REM: the level being coded and the caller's mask policy (range / attention-mask selection)
     int step0, step1;                           // chain steps to run: [0,10) base, [10,20) enhancement
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
@@ -1076,6 +1129,86 @@ int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, 
     return pc_quantile_thr_launch(m, SLICE, nb, k.HW, SLICE, k.q, thr, nullptr, st, (int64_t)D0 * k.HW);
 }
 
+// ResidualBlock (models/utils.py:59-87): leaky(conv2(leaky(conv1(x)))) + (skip(x) or x)
+int rem_rb(hipStream_t st, const RbW& r, std::initializer_list<Seg> segs, const float* x_single, int ld_x, int B, int h, int w, float* t1, float* ts,
+           float* out)
+{
+    const int co = r.c1.Cout;
+    PCCHK(conv(st, r.c1, segs, B, h, w, 1, t1, co, PC_EPI_LEAKY));
+    const float* idn = x_single;
+    int ld_i = ld_x;
+    if (r.has_skip) { PCCHK(conv(st, r.skip, segs, B, h, w, 1, ts, co, PC_EPI_NONE)); idn = ts; ld_i = co; }
+    return conv(st, r.c2, {{t1, co, co}}, B, h, w, 1, out, co, PC_EPI_LEAKY_RES, idn, ld_i);
+}
+
+// apply_latent_enhancement (CHProgREM.py:375-428) + LatentRateReduction.forward (:74-86) for enhancement slice i, images [b0, b0+nb):
+// the predicted scale sc_i [nb*HW][32] is refined in place.  mu_std = False: the means are left alone.
+int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_t st, const std::string& tag)
+{
+    pc_codec* c = k.c;
+    const double q = k.quality;
+    if (!c->rem_n || q <= c->rem_check[0]) return PC_OK;                         // :399-400: nothing below the first check level
+    int lvl; double q_bar;                                                        // find_check_quality :446-466, index choice :402-417
+    if (c->rem_n == 1) { lvl = 0; q_bar = c->rem_check[0]; }
+    else if (q <= c->rem_check[1]) { lvl = 0; q_bar = c->rem_check[0]; }
+    else if (c->rem_n == 2) { lvl = 1; q_bar = c->rem_check[1]; }
+    else if (q <= c->rem_check[2]) { lvl = 1; q_bar = c->rem_check[1]; }
+    else { lvl = 2; q_bar = c->rem_check[2]; }
+    const LrrW& L = c->rem[(size_t)lvl * NS0 + i];
+    const size_t pi = (size_t)k.HW, m = (size_t)nb * pi;
+    const int B = nb, h = k.h, w = k.w;
+    float *t1, *ts, *pa, *pb, *fp, *fl, *fb, *thr2;
+    PCCHK(c->buf("rem_t1" + tag, m * 64, &t1));
+    PCCHK(c->buf("rem_ts" + tag, m * 64, &ts));
+    PCCHK(c->buf("rem_pa" + tag, m * 64, &pa));
+    PCCHK(c->buf("rem_pb" + tag, m * 64, &pb));
+    PCCHK(c->buf("rem_fp" + tag, m * 32, &fp));
+    PCCHK(c->buf("rem_fl" + tag, m * 32, &fl));
+    PCCHK(c->buf("rem_fb" + tag, m * 32, &fb));
+    PCCHK(c->buf("rem_thr" + tag, (size_t)2 * k.B, &thr2));
+    // attention mask = round(star - bar), both thresholds on the UNREFINED scale (:386-396)
+    float qs = 0, qb = 0;
+    const int mode_star = mask_mode_for(k.mask_pol, q, &qs), mode_bar = mask_mode_for(k.mask_pol, q_bar, &qb);
+    if (mode_star == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qs, thr2, nullptr, st));
+    if (mode_bar == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qb, thr2 + k.B, nullptr, st));
+    const float* yb_i = img(k.yb, b0, pi * D0) + 32 * i;
+    const float* mu_b = k.mu + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;       // base step i: mu / scale kept per slice
+    const float* sd_b = k.scale + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;
+    // f_ent_prog = enc_enh_entropy_params(scale)
+    const float* x = sc_i; int ldx = SLICE;
+    for (int j = 0; j < L.n_sub; ++j) {
+        float* o = j == L.n_sub - 1 ? fp : (j & 1 ? pb : pa);
+        PCCHK(rem_rb(st, L.ent_enh[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
+        x = o; ldx = SLICE;
+    }
+    // f_latent = enc_base_rep(y_b_hat)
+    x = yb_i; ldx = D0;
+    for (int j = 0; j < L.n_sub; ++j) {
+        float* o = j == L.n_sub - 1 ? fl : (j & 1 ? pb : pa);
+        PCCHK(rem_rb(st, L.base_rep[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
+        x = o; ldx = SLICE;
+    }
+    // f_ent_base = enc_base_entropy_params(cat(mu_base, std_base))
+    PCCHK(rem_rb(st, L.ent_base[0], {{mu_b, SLICE, SLICE}, {sd_b, SLICE, SLICE}}, nullptr, 0, B, h, w, t1, ts, L.n_sub == 1 ? fb : pa));
+    x = pa; ldx = SLICE;
+    for (int j = 1; j < L.n_sub; ++j) {
+        float* o = j == L.n_sub - 1 ? fb : (j & 1 ? pb : pa);
+        PCCHK(rem_rb(st, L.ent_base[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
+        x = o;
+    }
+    // ret = enc(cat(f_latent, f_ent_base, f_ent_prog))   (:80)
+    PCCHK(rem_rb(st, L.enc[0], {{fl, SLICE, SLICE}, {fb, SLICE, SLICE}, {fp, SLICE, SLICE}}, nullptr, 0, B, h, w, t1, ts, pa));
+    x = pa;
+    for (int j = 1; j < L.n_enc; ++j) {
+        float* o = (j & 1) ? pb : pa;
+        const int ci = L.enc[j].c1.Cin;
+        PCCHK(rem_rb(st, L.enc[j], {{x, ci, ci}}, x, ci, B, h, w, t1, ts, o));
+        x = o;
+    }
+    // scale <- ret * att + scale   (:81-85)
+    return pc_rem_combine_launch(x, SLICE, sc_i, SLICE, nb, k.HW, thr2, mode_star, thr2 + k.B, mode_bar, st);
+}
+
 // mean / scale stacks (+ quantile threshold) of chain step `step` (0..9 base, 10..19 enhancement) for images [b0, b0+nb)
 int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hipStream_t sB, hipEvent_t eA, hipEvent_t eB,
                  const std::string& tag)
@@ -1096,6 +1229,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
             const int i = step - NS0, s = std::min(5, i);
             PCCHK(stack5_pair(c, sA, c->cc_mean_p[i], c->cc_scale_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}},
                               ls + D0, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
+            PCCHK(rem_refine(k, i, b0, nb, sc_i, sA, tag));                           // REM: refined scale before the mask (CHProgREM.py:812-826)
             if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sA));
         }
         return PC_OK;
@@ -1110,6 +1244,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
         const int i = step - NS0, s = std::min(5, i);
         PCCHK(stack5(c, sA, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
         PCCHK(stack5(c, sB, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
+        PCCHK(rem_refine(k, i, b0, nb, sc_i, sB, tag));
         if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sB));   // :819-824
     }
     if (two) { HIPCHK(hipEventRecord(eB, sB)); HIPCHK(hipStreamWaitEvent(sA, eB, 0)); }
@@ -1206,12 +1341,18 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
                                 c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA,
                                 (e && k.cust_map) ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi,
                                 k.idx8 + so));
+        static const bool slow_dec = [] { const char* v = std::getenv("PC_DEC_FAST"); return v && std::atoi(v) == 0; }();   // A/B switch
         uint8_t* h_idx8 = reinterpret_cast<uint8_t*>(h_idx);
-        HIPCHK(hipMemcpyAsync(h_idx8, k.idx8 + so, per * nb, hipMemcpyDeviceToHost, sA));
+        if (slow_dec) HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
+        else HIPCHK(hipMemcpyAsync(h_idx8, k.idx8 + so, per * nb, hipMemcpyDeviceToHost, sA));
         HIPCHK(hipStreamSynchronize(sA));
         const auto td0 = std::chrono::steady_clock::now();
         const size_t slot = e ? (size_t)NS0 + (size_t)NS0 * k.level + i : (size_t)step;
-        PCCHK(pc::rans_decode_u8_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx8, per, c->gc.dec(), h_sym, nt));   // :894,969
+        if (slow_dec)
+            PCCHK(pc_rans_decode_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx, per, c->gc.cdf.data(), c->gc.n, c->gc.stride,
+                                       c->gc.len.data(), c->gc.off.data(), h_sym, nt));
+        else
+            PCCHK(pc::rans_decode_u8_batch(y_strings + slot * k.B + b0, y_lens + slot * k.B + b0, nb, h_idx8, per, c->gc.dec(), h_sym, nt));   // :894,969
         { std::lock_guard<std::mutex> lk(c->buf_mu); c->t_host_decode_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - td0).count(); }
         HIPCHK(hipMemcpyAsync(k.sym + so, h_sym, per * nb * 4, hipMemcpyHostToDevice, sA));
         float* dst = e ? img(k.ye, b0, pi * D0) + 32 * i : img(k.yb, b0, pi * D0) + 32 * i;
@@ -1427,6 +1568,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data();
         ke.enh = true; ke.level = first_coded; ke.waitv = c->pipe_ev.data();
         ke.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[first_coded], &ke.q);
+        ke.quality = qualities[first_coded]; ke.mask_pol = mask_pol;
         ke.masks = masks_out ? masks_out[first_coded] : nullptr;
         if (can_stream && first_coded == last_coded) { ke.so_sym = c->h_sym + n_half; ke.so_idx = c->h_idx + n_half; }
         for (int t = 0; t <= NS0; ++t) {
@@ -1474,6 +1616,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         if (qualities[l] <= 0) continue;                                                 // base only: nothing level-specific to code
         k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
         k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);   // a custom map overrides the policy
+        k.quality = qualities[l]; k.mask_pol = mask_pol;
         k.masks = masks_out ? masks_out[l] : nullptr;
         const int bufsel = n_coded & 1;
         const size_t off = (size_t)(1 + bufsel) * n_half;
@@ -1634,6 +1777,7 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
         kb.enh = false; kb.mode = 0; kb.sig = c->pipe_ev.data();
         ke.enh = true; ke.level = 0; ke.waitv = c->pipe_ev.data(); ke.masks = masks_out;
         ke.mode = mask_mode_for(mask_pol, quality, &ke.q);
+        ke.quality = quality; ke.mask_pol = mask_pol;
         for (int t = 0; t <= NS0; ++t) {
             if (t < NS0) { kb.step0 = t; kb.step1 = t + 1; PCCHK(encode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA")); }                       // :1033-1061
             if (t >= 1) { ke.step0 = NS0 + t - 1; ke.step1 = NS0 + t; PCCHK(encode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB")); }   // :1089-1160
@@ -1646,6 +1790,7 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
         if (enh) {
             k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = 0;
             k.mode = mask_mode_for(mask_pol, quality, &k.q);
+            k.quality = quality; k.mask_pol = mask_pol;
             k.masks = masks_out;
             PCCHK(run_chain(k, st, false, nullptr, nullptr));                            // :1089-1160
         }
@@ -1724,6 +1869,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         ke.step0 = NS0; ke.step1 = 2 * NS0; ke.enh = true; ke.level = first_enh; ke.waitv = c->pipe_ev.data(); ke.wait_count = &recorded;
         ke.h_off = per * B;
         ke.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[first_enh], &ke.q);
+        ke.quality = qualities[first_enh]; ke.mask_pol = mask_pol;
         int rb = PC_OK;
         std::thread tb([&] {
             rb = decode_lane(kb, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt);                  // :874-904
@@ -1752,6 +1898,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         if (!(piped && l == first_enh)) {
             k.step0 = NS0; k.step1 = 2 * NS0; k.enh = true; k.level = l;
             k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);
+            k.quality = qualities[l]; k.mask_pol = mask_pol;
             PCCHK(run_chain(k, st, true, y_strings, y_lens));                            // :930-983
         }
         PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990

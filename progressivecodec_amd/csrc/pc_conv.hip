@@ -59,10 +59,12 @@ __device__ __forceinline__ float epilogue_apply(int epi, float v, float a0, floa
     case PC_EPI_CLAMP01: return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
     case PC_EPI_LRP: return a0 + 0.5f * pc_tanhf(v);
     case PC_EPI_LRP_ADD: return (a0 + 0.5f * pc_tanhf(v)) + a1;
+    case PC_EPI_LEAKY: return v > 0.0f ? v : v * 0.01f;
+    case PC_EPI_LEAKY_RES: return (v > 0.0f ? v : v * 0.01f) + a0;
     default: return v;
     }
 }
-__device__ __forceinline__ bool epilogue_uses_aux0(int epi) { return epi == PC_EPI_RES_GELU || epi == PC_EPI_RES || epi == PC_EPI_GATE || epi == PC_EPI_GDN || epi == PC_EPI_IGDN || epi == PC_EPI_LRP || epi == PC_EPI_LRP_ADD; }
+__device__ __forceinline__ bool epilogue_uses_aux0(int epi) { return epi == PC_EPI_RES_GELU || epi == PC_EPI_RES || epi == PC_EPI_GATE || epi == PC_EPI_GDN || epi == PC_EPI_IGDN || epi == PC_EPI_LRP || epi == PC_EPI_LRP_ADD || epi == PC_EPI_LEAKY_RES; }
 __device__ __forceinline__ bool epilogue_uses_aux1(int epi) { return epi == PC_EPI_GATE || epi == PC_EPI_LRP_ADD; }
 
 __device__ __forceinline__ float epilogue_value(const pc_conv_params& p, float v, int64_t pix, int n)

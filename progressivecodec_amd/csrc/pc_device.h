@@ -21,6 +21,8 @@ enum {
     PC_EPI_CLAMP01 = 7,   // x_hat.clamp_(0, 1)                                   CHProg_cnn.py:909,988
     PC_EPI_LRP = 8,       // y_hat + 0.5 * tanh(lrp)                              CHProg_cnn.py:759-762
     PC_EPI_LRP_ADD = 9,   // (y_hat + 0.5 * tanh(lrp)) + base  (merge "res")      CHProg_cnn.py:837-843
+    PC_EPI_LEAKY = 10,    // nn.LeakyReLU() (slope 0.01)                          models/utils.py:65,79
+    PC_EPI_LEAKY_RES = 11,// ResidualBlock tail: leaky(conv2) + identity          models/utils.py:80-86
 };
 
 enum { PC_TILE_AUTO = 0, PC_TILE_128x128 = 1, PC_TILE_64x64 = 2, PC_TILE_128x32 = 3 };
@@ -114,6 +116,11 @@ int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream); // 
 int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work,
                            hipStream_t stream, int64_t batch_stride = 0);   // batch_stride 0: HW * ld
 size_t pc_quantile_work_bytes(int B);
+
+// REM (models/CHProgREM.py:84-86,395-401): scale <- ret * round(star - bar) + scale, the two masks thresholding the UNREFINED scale
+// (mode 1: value >= thr[b]; 2: ones; 3: zeros).  ret / scale NHWC [B][HW][32] with pixel strides.
+int pc_rem_combine_launch(const float* ret, int ld_ret, float* scale, int ld_scale, int B, int HW, const float* thr_star, int mode_star,
+                          const float* thr_bar, int mode_bar, hipStream_t stream);
 
 int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* medians, int32_t* sym, float* zhat,
                        hipStream_t stream);

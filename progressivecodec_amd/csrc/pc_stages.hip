@@ -522,6 +522,23 @@ __global__ void eb_dequant_kernel(const int32_t* __restrict__ sym, int B, int HW
     }
 }
 
+// REM: refined scale = ret * att + scale, att = round(star - bar) with both masks taken on the unrefined scale (CHProgREM.py:395-401, :84-86)
+__global__ void rem_combine_kernel(const float* __restrict__ ret, int ld_ret, float* __restrict__ scale, int ld_scale, int B, int HW,
+                                   const float* __restrict__ thr_star, int mode_star, const float* __restrict__ thr_bar, int mode_bar)
+{
+    const int64_t n = (int64_t)B * HW * 32;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e & 31);
+        const int64_t pix = e >> 5;
+        const int b = (int)(pix / HW);
+        const float s = scale[pix * ld_scale + c];
+        const float star = mode_star == 1 ? (s >= thr_star[b] ? 1.0f : 0.0f) : (mode_star == 2 ? 1.0f : 0.0f);
+        const float bar = mode_bar == 1 ? (s >= thr_bar[b] ? 1.0f : 0.0f) : (mode_bar == 2 ? 1.0f : 0.0f);
+        const float att = pc_roundevenf(star - bar);
+        scale[pix * ld_scale + c] = ret[pix * ld_ret + c] * att + s;
+    }
+}
+
 }  // namespace
 
 #define PC_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP)
@@ -651,5 +668,15 @@ int pc_eb_dequant_launch(const int32_t* sym, int B, int HW, int C, const float* 
     const int64_t n = (int64_t)B * HW * C;
     const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
     hipLaunchKernelGGL(eb_dequant_kernel, dim3(blocks), dim3(256), 0, stream, sym, B, HW, C, med, zhat);
+    return PC_LAUNCH_CHECK();
+}
+
+int pc_rem_combine_launch(const float* ret, int ld_ret, float* scale, int ld_scale, int B, int HW, const float* thr_star, int mode_star,
+                          const float* thr_bar, int mode_bar, hipStream_t stream)
+{
+    if (!ret || !scale || B <= 0 || HW <= 0 || (mode_star == 1 && !thr_star) || (mode_bar == 1 && !thr_bar)) return PC_ERR_ARG;
+    const int64_t n = (int64_t)B * HW * 32;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(rem_combine_kernel, dim3(blocks), dim3(256), 0, stream, ret, ld_ret, scale, ld_scale, B, HW, thr_star, mode_star, thr_bar, mode_bar);
     return PC_LAUNCH_CHECK();
 }

@@ -118,8 +118,13 @@ class ChannelProgresssiveWACNN(_module_base()):
         for _, b in self.named_buffers():
             yield b
 
-    def load_state_dict(self, state_dict, strict=True):
-        """models/cnn.py:195-202 / base.py:62-70: accepts the reference's 1019-key state_dict."""
+    def load_state_dict(self, state_dict, strict=True, _extra=None):
+        """models/cnn.py:195-202 / base.py:62-70: accepts the reference's 1019-key state_dict.  (_extra: tensors of a wrapping model --
+        the REM's post_latent.* -- handed to the native codec before it is finalised.)"""
+        for k, a in (_extra or {}).items():
+            a = np.ascontiguousarray(a, np.float32)
+            shp = (C.c_int64 * a.ndim)(*a.shape)
+            check(lib().pc_codec_set_tensor(self._h, k.encode(), a.ctypes.data_as(C.c_void_p), _DT["float32"], shp, a.ndim), f"set_tensor({k})")
         spec = param_spec(self.cfg)
         missing = [k for k in spec if k not in state_dict]
         unexpected = [k for k in state_dict if k not in spec]
@@ -382,6 +387,13 @@ class ChannelProgresssiveWACNN(_module_base()):
             raise ValueError("Invalid strings or indexes parameters")
         x_hat = self._decompress_packed(slots, z_strings, B, zh, zw, qualities, mask_pol)
         return [{"x_hat": x_hat[lv]} for lv in range(L)]
+
+    def read_latent(self, name, B, h, w):
+        """the decoded latent of the last call ("yhat_base" / "yhat_enh": NHWC [B*h*w][320] inside the codec) as a host tensor
+        [B, 320, h, w] -- the "y_hat" entry of the REM's dictionaries (CHProgREM.py:888,1122)"""
+        import torch
+        a = self.read_tap(name)[: B * h * w * 320].reshape(B, h, w, 320)
+        return torch.from_numpy(np.ascontiguousarray(a.transpose(0, 3, 1, 2)))
 
     # ------------------------------------------------------------------ test taps
     def read_tap(self, name, dtype=np.float32):

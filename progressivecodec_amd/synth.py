@@ -133,3 +133,25 @@ def synthetic_state_dict(cfg: CodecConfig = CodecConfig(), seed: int = 0, as_tor
         import torch
         return OrderedDict((k, torch.from_numpy(v)) for k, v in out.items())
     return out
+
+
+def synthetic_post_state_dict(check_multiple: int = 3, dimension: str = "big", seed: int = 0, as_torch: bool = True):
+    """Deterministic weights for PostRateProcessedNetwork.post_latent (reference models/CHProgREM.py:227-234) in its own state-dict
+    layout ("<level>.<slice>.<subnet>.<block>.conv1.weight" ...).  Fan-in scaled; the last block of `enc` is damped so that the
+    refinement moves the predicted scale by a fraction of itself (an untrained net would otherwise swamp it)."""
+    from .arch import rem_param_spec
+    out = OrderedDict()
+    for name, (shape, dtype, kind) in rem_param_spec(check_multiple, dimension).items():
+        g = _rng("post_latent." + name, seed)
+        if kind == "conv_w":
+            co, ci, kh, kw = shape
+            v = g.standard_normal(shape) * math.sqrt(1.0 / (ci * kh * kw))
+            if ".enc.3." in name or (dimension != "big" and ".enc.2." in name):
+                v = v * 0.5
+        else:
+            v = g.standard_normal(shape) * 0.02
+        out[name] = np.ascontiguousarray(np.asarray(v).astype(dtype))
+    if as_torch:
+        import torch
+        return OrderedDict((k, torch.from_numpy(v)) for k, v in out.items())
+    return out

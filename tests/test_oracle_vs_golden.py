@@ -247,3 +247,40 @@ def test_force_enhanced_torch_backend_equals_reference(idx):
     assert abs(float(-torch.log2(ly.double()).sum()) - c["bits_y"]) <= 1e-9 * c["bits_y"]
     assert sha(out["x_hat"].numpy().tobytes()) == c["x_hat_sha"]
     assert all(int(m.sum()) == 0 for m in out["masks"])
+
+
+# ------------------------------------------------------------------ REM model family
+def _rem_cases():
+    return json.load(open(os.path.join(os.path.dirname(__file__), "golden", "rem.json")))
+
+
+@functools.lru_cache(maxsize=None)
+def rem_post_sd():
+    from progressivecodec_amd.synth import synthetic_post_state_dict
+    return synthetic_post_state_dict(3, "big")
+
+
+def rem_oracle(backend):
+    from oracle.codec_ref import RemCodec
+    return RemCodec(synth_sd(), rem_post_sd(), backend)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 3, 4, 5])
+def test_rem_torch_backend_equals_reference(idx):
+    """PostRateProcessedNetwork.compress()/decompress() (CHProgREM.py:673,896): every byte string, mask popcount, the refined scale
+    of slice 3 and the x_hat hash of the reference (tests/golden/make_golden_rem.py) reproduced by the oracle's ATen back-end --
+    below the first check level (no refinement), inside each of the three refinement ranges, and at quality 10."""
+    c = _rem_cases()[idx]
+    torch.set_num_threads(8)
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    orc = rem_oracle("torch")
+    taps = {}
+    out = orc.compress(x, c["quality"], taps=taps)
+    ys, zs = out["strings"]
+    assert [sha(s) for s in zs] == c["z_sha"]
+    assert [[sha(s) for s in sl] for sl in ys] == c["y_sha"]
+    assert [[int(m[b].sum()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    assert np.array_equal(taps["e3"]["scale"].flatten()[::37].numpy(), np.asarray(c["scale3_sub"], np.float32))
+    dec = orc.decompress(out["strings"], out["shape"], c["quality"])["x_hat"].clamp(0, 1)
+    assert sha(dec.numpy().tobytes()) == c["x_hat_sha"]
+    assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) < 1e-12
