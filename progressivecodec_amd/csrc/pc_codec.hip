@@ -1121,12 +1121,22 @@ int lane_count(const pc_codec* c, int B, bool decode)
 
 // per-image mask threshold of enhancement slice i (layers/masking.py:205-223): the (1 - pr/10) quantile of the slice's scale, or of
 // the caller's custom map when one was given (:171-194; its slice is a flat [32*HW] run per image, NCHW)
-int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, hipStream_t st)
+// scratch of the large-image quantile path (null for slices the single-workgroup kernel handles): per lane, reused across steps
+int quantile_work(const ChainCtx& k, int nb, const std::string& tag, uint32_t** w)
+{
+    *w = nullptr;
+    if ((int64_t)k.HW * SLICE <= PC_QUANTILE_SMALL_N) return PC_OK;
+    return k.c->buf("qwork" + tag, pc_quantile_work_bytes(nb) / sizeof(uint32_t), w);
+}
+
+int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, hipStream_t st, const std::string& tag)
 {
     float* thr = k.thr + (size_t)i * k.B + b0;
-    if (!k.cust_map) return pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, thr, nullptr, st);
+    uint32_t* w;
+    PCCHK(quantile_work(k, nb, tag, &w));
+    if (!k.cust_map) return pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, k.q, thr, w, st);
     const float* m = k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * k.HW;
-    return pc_quantile_thr_launch(m, SLICE, nb, k.HW, SLICE, k.q, thr, nullptr, st, (int64_t)D0 * k.HW);
+    return pc_quantile_thr_launch(m, SLICE, nb, k.HW, SLICE, k.q, thr, w, st, (int64_t)D0 * k.HW);
 }
 
 // ResidualBlock (models/utils.py:59-87): leaky(conv2(leaky(conv1(x)))) + (skip(x) or x)
@@ -1169,8 +1179,10 @@ int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_
     // attention mask = round(star - bar), both thresholds on the UNREFINED scale (:386-396)
     float qs = 0, qb = 0;
     const int mode_star = mask_mode_for(k.mask_pol, q, &qs), mode_bar = mask_mode_for(k.mask_pol, q_bar, &qb);
-    if (mode_star == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qs, thr2, nullptr, st));
-    if (mode_bar == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qb, thr2 + k.B, nullptr, st));
+    uint32_t* qw;
+    PCCHK(quantile_work(k, nb, tag, &qw));
+    if (mode_star == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qs, thr2, qw, st));
+    if (mode_bar == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qb, thr2 + k.B, qw, st));
     const float* yb_i = img(k.yb, b0, pi * D0) + 32 * i;
     const float* mu_b = k.mu + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;       // base step i: mu / scale kept per slice
     const float* sd_b = k.scale + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;
@@ -1230,7 +1242,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
             PCCHK(stack5_pair(c, sA, c->cc_mean_p[i], c->cc_scale_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}},
                               ls + D0, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
             PCCHK(rem_refine(k, i, b0, nb, sc_i, sA, tag));                           // REM: refined scale before the mask (CHProgREM.py:812-826)
-            if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sA));
+            if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sA, tag));
         }
         return PC_OK;
     }
@@ -1245,7 +1257,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
         PCCHK(stack5(c, sA, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
         PCCHK(stack5(c, sB, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
         PCCHK(rem_refine(k, i, b0, nb, sc_i, sB, tag));
-        if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sB));   // :819-824
+        if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sB, tag));   // :819-824
     }
     if (two) { HIPCHK(hipEventRecord(eB, sB)); HIPCHK(hipStreamWaitEvent(sA, eB, 0)); }
     return PC_OK;

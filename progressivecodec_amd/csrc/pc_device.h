@@ -116,6 +116,7 @@ int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream); // 
 int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work,
                            hipStream_t stream, int64_t batch_stride = 0);   // batch_stride 0: HW * ld
 size_t pc_quantile_work_bytes(int B);
+#define PC_QUANTILE_SMALL_N 32768   // up to here one workgroup per image holds the keys in registers and `work` is not used
 
 // REM (models/CHProgREM.py:84-86,395-401): scale <- ret * round(star - bar) + scale, the two masks thresholding the UNREFINED scale
 // (mode 1: value >= thr[b]; 2: ones; 3: zeros).  ret / scale NHWC [B][HW][32] with pixel strides.

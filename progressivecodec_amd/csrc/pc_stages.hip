@@ -272,101 +272,151 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
 }
 
 // ---- multi-block path for large images (n > 32768): the single-workgroup kernel above reads an image five times from one CU.
-// Here (1) G workgroups per image build a 4096-bin histogram of the keys' top 12 bits, (2) one workgroup finds the bins holding the
-// two ranks, (3) G workgroups collect the keys of those bins (a few percent of the image) into a candidate list, (4) one workgroup
-// runs the exact register-resident select on the candidates.  Two passes over the data instead of five, spread over the chip.
-// work (uint32 per image, stride PC_QW_STRIDE): [0,4096) histogram, then nan count, candidate count, bin_lo, bin_hi, less, pad[3],
-// then up to PC_QW_CAP candidate keys; more candidates than that (degenerate data) fall back to the generic select in step 4.
-#define PC_QW_BINS 4096
+// Here the image is read ONCE, spread over the chip:
+//  (1) one workgroup per image reads 4096 sample keys (256 runs of 16 consecutive elements) and picks, by a 12 + 8 bit radix
+//      select on the samples, a key bracket [a, b] that holds the two wanted ranks with high probability (sample ranks q*m -/+ a
+//      margin of several standard deviations);
+//  (2) G workgroups per image stream the image with 16-byte loads, count the keys below a and the NaNs, and append the keys inside
+//      [a, b] (a few percent of the image) to a candidate list -- one global atomic per workgroup and 16 K elements;
+//  (3) one workgroup runs the exact register-resident select on the candidates.  The sample only steers: (3) checks that both ranks
+//      fall inside the candidates (less <= lo, hi < less + count, count <= capacity) and otherwise -- a bad bracket, or more ties at
+//      the quantile than the list holds -- falls back to the generic select over the whole image, so the result is always the exact
+//      order statistic.
+// work (uint32 per image, stride PC_QW_STRIDE): nan count, candidate count, key a, key b, less, pad[3], then PC_QW_CAP candidates.
 #define PC_QW_CAP 32768
-#define PC_QW_HDR (PC_QW_BINS + 8)
+#define PC_QW_HDR 8
 #define PC_QW_STRIDE (PC_QW_HDR + PC_QW_CAP)
+#define PC_QW_M 4096
+#define PC_QW_STEP 4096
 
-__global__ void quantile_zero_kernel(uint32_t* __restrict__ work)
+// rank r (0-based) of the 4096 sample keys held 16 per thread by 256 threads -> the 20-bit key prefix (key >> 12) that holds it
+__device__ __forceinline__ uint32_t sample_prefix(const uint32_t (&k)[16], uint32_t r, uint32_t* hist /* 4096 */, uint32_t* sh /* 4 */)
 {
-    uint32_t* w = work + (size_t)blockIdx.x * PC_QW_STRIDE;
-    for (int k = threadIdx.x; k < PC_QW_HDR; k += blockDim.x) w[k] = 0;
-}
-
-__global__ __launch_bounds__(1024) void quantile_hist_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
-                                                            uint32_t* __restrict__ work)
-{
-    __shared__ uint32_t h[PC_QW_BINS];
-    const int b = blockIdx.y, tid = threadIdx.x;
-    for (int k = tid; k < PC_QW_BINS; k += 1024) h[k] = 0;
-    __syncthreads();
-    const int64_t n = (int64_t)HW * C;
-    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
-    const float* base = scale + (int64_t)b * sb;
-    uint32_t nanl = 0;
-    for (int64_t e = e0 + tid; e < e1; e += 1024) {
-        const int64_t p = e / C;
-        const float f = base[p * ld + (e - p * C)];
-        if (f != f) nanl++;
-        atomicAdd(&h[fkey(f) >> 20], 1u);
-    }
-    __syncthreads();
-    uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
-    for (int k = tid; k < PC_QW_BINS; k += 1024) if (h[k]) atomicAdd(&w[k], h[k]);
-    if (nanl) atomicAdd(&w[PC_QW_BINS], nanl);
-}
-
-__global__ __launch_bounds__(256) void quantile_pick_kernel(int64_t n, float q, uint32_t* __restrict__ work)
-{
-    __shared__ uint32_t part[256];
-    uint32_t* w = work + (size_t)blockIdx.x * PC_QW_STRIDE;
-    const int tid = threadIdx.x;
-    uint32_t mine = 0;
-    for (int k = 0; k < 16; ++k) mine += w[16 * tid + k];
-    part[tid] = mine;
-    __syncthreads();
-    if (tid == 0) {
-        const float rank = q * (float)(n - 1);
-        const uint32_t lo = (uint32_t)floorf(rank), hi = (uint32_t)ceilf(rank);
-        uint32_t acc = 0, bin_lo = PC_QW_BINS - 1, bin_hi = PC_QW_BINS - 1, less = 0;
-        bool got_lo = false, got_hi = false;
-        for (int t = 0; t < 256 && !got_hi; ++t) {
-            if (acc + part[t] <= lo && (got_lo || acc + part[t] <= hi)) { acc += part[t]; continue; }
-            for (int k = 0; k < 16 && !got_hi; ++k) {
-                const uint32_t c = w[16 * t + k];
-                if (!got_lo && lo < acc + c) { got_lo = true; bin_lo = 16 * t + k; less = acc; }
-                if (got_lo && hi < acc + c) { got_hi = true; bin_hi = 16 * t + k; }
-                acc += c;
-            }
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t prefix = 0, mask = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int bits = pass == 0 ? 12 : 8, shift = pass == 0 ? 20 : 12, nb = 1 << bits, per = nb / 256;
+        for (int i = tid; i < nb; i += 256) hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if ((k[i] & mask) == prefix) atomicAdd(&hist[(k[i] >> shift) & (nb - 1)], 1u);
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int i = 0; i < per; ++i) mine += hist[per * tid + i];
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += o; }
+        if (lane == 63) sh[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0;
+        for (int i = 0; i < wv; ++i) before += sh[i];
+        const uint32_t excl = before + incl - mine;
+        __syncthreads();
+        if (r >= excl && r < excl + mine) {                     // exactly one thread: the rank lies in its bins
+            uint32_t rr = r - excl, d = per * tid;
+            for (int i = 0; i < per; ++i) { const uint32_t h = hist[per * tid + i]; if (rr < h) break; rr -= h; d++; }
+            sh[0] = prefix | (d << shift); sh[1] = rr;
         }
-        w[PC_QW_BINS + 2] = bin_lo; w[PC_QW_BINS + 3] = bin_hi; w[PC_QW_BINS + 4] = less;
+        __syncthreads();
+        prefix = sh[0]; r = sh[1];
+        mask |= (uint32_t)(nb - 1) << shift;
+        __syncthreads();
+    }
+    return prefix >> 12;
+}
+
+__global__ __launch_bounds__(256) void quantile_sample_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q, int64_t sb,
+                                                             uint32_t* __restrict__ work)
+{
+    __shared__ uint32_t hist[4096];
+    __shared__ uint32_t sh[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t n = (int64_t)HW * C;
+    const float* base = scale + (int64_t)b * sb;
+    const int64_t start = (int64_t)tid * ((n - 16) / 255);
+    uint32_t k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t e = start + i, p = e / C;
+        k[i] = fkey(base[p * ld + (e - p * C)]);
+    }
+    // sample ranks around q * (m - 1): margin = 7 standard deviations of a binomial sample quantile (the runs of 16 are correlated,
+    // so count on half the nominal sample size) + 8
+    const float m1 = (float)(PC_QW_M - 1);
+    const float c = q * m1, sd = sqrtf(fmaxf(q * (1.0f - q), 0.0f) * (float)PC_QW_M);
+    const float mg = 7.0f * sd + 8.0f;
+    const float fa = floorf(c - mg), fb = ceilf(c + mg);
+    uint32_t ka = 0u, kb = 0xffffffffu;
+    if (fa > 0.0f) ka = sample_prefix(k, (uint32_t)fa, hist, sh) << 12;
+    if (fb < m1) kb = (sample_prefix(k, (uint32_t)fb, hist, sh) << 12) | 0xfffu;
+    if (tid == 0) {
+        uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+        w[0] = 0; w[1] = 0; w[2] = ka; w[3] = kb; w[4] = 0;
     }
 }
 
-__global__ __launch_bounds__(1024) void quantile_collect_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
-                                                               uint32_t* __restrict__ work)
+template <bool VEC>
+__global__ __launch_bounds__(256) void quantile_bracket_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
+                                                              uint32_t* __restrict__ work)
 {
-    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t sh_take[4], sh_less[4], sh_nan[4], sh_base;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
-    const uint32_t bin_lo = w[PC_QW_BINS + 2], bin_hi = w[PC_QW_BINS + 3];
+    const uint32_t ka = w[2], kb = w[3];
     uint32_t* cand = w + PC_QW_HDR;
     const int64_t n = (int64_t)HW * C;
-    const int64_t chunk = (n + gridDim.x - 1) / gridDim.x, e0 = blockIdx.x * chunk, e1 = e0 + chunk < n ? e0 + chunk : n;
     const float* base = scale + (int64_t)b * sb;
-    for (int64_t eb = e0; eb < e1; eb += 1024) {              // uniform trip count: the ballot needs the whole wave
-        const int64_t e = eb + tid;
-        uint32_t k = 0;
-        bool take = false;
-        if (e < e1) {
-            const int64_t p = e / C;
-            k = fkey(base[p * ld + (e - p * C)]);
-            const uint32_t bin = k >> 20;
-            take = bin == bin_lo || bin == bin_hi;
+    // 4 K elements per step: thread t owns elements e0 + 4 * (t + 256 * i) .. + 3, i < 4; all 16-byte loads in flight before the first use
+    for (int64_t e0 = (int64_t)blockIdx.x * PC_QW_STEP; e0 < n; e0 += (int64_t)gridDim.x * PC_QW_STEP) {
+        uint32_t k[16];
+        bool in[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t e = e0 + 4 * (tid + 256 * (int64_t)i);
+            if (VEC) {
+                const int64_t p = e / C;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < n) v = *reinterpret_cast<const float4*>(base + p * ld + (e - p * C));    // n % 4 == 0: whole quad or nothing
+                k[4 * i] = fkey(v.x); k[4 * i + 1] = fkey(v.y); k[4 * i + 2] = fkey(v.z); k[4 * i + 3] = fkey(v.w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in[4 * i + j] = e < n;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int64_t ee = e + j, p = ee / C;
+                    in[4 * i + j] = ee < n;
+                    k[4 * i + j] = in[4 * i + j] ? fkey(base[p * ld + (ee - p * C)]) : 0u;
+                }
+            }
         }
-        const unsigned long long m = __ballot(take);
-        if (m) {
-            uint32_t start = 0;
-            const int leader = __ffsll((long long)m) - 1;
-            if (lane == leader) start = atomicAdd(&w[PC_QW_BINS + 1], (uint32_t)__popcll(m));
-            start = (uint32_t)__shfl((int)start, leader);
-            const uint32_t idx = start + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (take && idx < PC_QW_CAP) cand[idx] = k;
+        uint32_t take = 0, less = 0, nan = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            take += in[i] && k[i] >= ka && k[i] <= kb;
+            less += in[i] && k[i] < ka;
+            nan += in[i] && (k[i] > 0xff800000u || k[i] < 0x007fffffu);      // keys of +NaN lie above +inf's, of -NaN below -inf's
         }
+        uint32_t incl = take;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += o; }
+        for (int off = 32; off; off >>= 1) { less += (uint32_t)__shfl_xor((int)less, off); nan += (uint32_t)__shfl_xor((int)nan, off); }
+        if (lane == 63) sh_take[wv] = incl;
+        if (lane == 0) { sh_less[wv] = less; sh_nan[wv] = nan; }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t tt = sh_take[0] + sh_take[1] + sh_take[2] + sh_take[3];
+            const uint32_t tl = sh_less[0] + sh_less[1] + sh_less[2] + sh_less[3], tn = sh_nan[0] + sh_nan[1] + sh_nan[2] + sh_nan[3];
+            sh_base = tt ? atomicAdd(&w[1], tt) : 0u;
+            if (tl) atomicAdd(&w[4], tl);
+            if (tn) atomicAdd(&w[0], tn);
+        }
+        uint32_t before = 0;
+        for (int i = 0; i < wv; ++i) before += sh_take[i];
+        __syncthreads();
+        uint32_t pos = sh_base + before + incl - take;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (in[i] && k[i] >= ka && k[i] <= kb) { if (pos < PC_QW_CAP) cand[pos] = k[i]; pos++; }
+        }
+        __syncthreads();
     }
 }
 
@@ -376,8 +426,12 @@ __global__ __launch_bounds__(1024) void quantile_final_kernel(const float* __res
     const int b = blockIdx.x;
     const uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
     const int64_t n = (int64_t)HW * C;
-    const uint32_t cnt = w[PC_QW_BINS + 1];
-    if (cnt <= PC_QW_CAP) quantile_block<32, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, w[PC_QW_BINS + 4], w[PC_QW_BINS], q, thr + b);
+    const uint32_t cnt = w[1], less = w[4];
+    const float rank = q * (float)(n - 1);
+    const uint32_t lo = (uint32_t)floorf(rank), hi = (uint32_t)ceilf(rank);
+    const bool ok = less <= lo && hi < less + cnt;
+    if (ok && cnt <= 8192) quantile_block<8, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, less, w[0], q, thr + b);
+    else if (ok && cnt <= PC_QW_CAP) quantile_block<32, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, less, w[0], q, thr + b);
     else quantile_block<0, false>(scale + (int64_t)b * sb, ld, C, nullptr, n, n, 0u, 0u, q, thr + b);
 }
 
@@ -392,6 +446,22 @@ __device__ __forceinline__ int gc_index(float s, const float* table, int nt, flo
     int lo = 0, hi = nt - 1;                   // first k in [0, nt-1) with table[k] >= s
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (table[mid] < s) lo = mid + 1; else hi = mid; }
     return lo;
+}
+// the same count for a table held as 64 LDS words, entries from nt-1 on replaced by +inf (pc_fill_table64): six uniform steps, no
+// data-dependent loop, so the searches of a thread's elements overlap their LDS latencies.  Ascending tables only (as gc_index).
+__device__ __forceinline__ int gc_index64(float s, const float* t64, int nt, float bound)
+{
+    const bool isnan = s != s;
+    s = s > bound ? s : bound;
+    int lo = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1) lo += (t64[lo + step - 1] < s) ? step : 0;      // lo + step - 1 <= 62
+    return isnan ? nt - 1 : lo;
+}
+__device__ __forceinline__ void pc_fill_table64(float* t64, const float* table, int nt)
+{
+    const int tid = threadIdx.x;
+    if (tid < 64) t64[tid] = tid < nt - 1 ? table[tid] : __builtin_inff();
 }
 
 // GaussianConditional._likelihood of an already rounded value (entropy_models.py:626-643, :578-582), the way the reference's eval
@@ -492,6 +562,130 @@ __global__ __launch_bounds__(256) void gc_dequant_kernel(const pc_prep_params p)
         const int64_t pix = (int64_t)b * p.HW + p0 + px;
         p.yhat[pix * p.ld_yhat + c] = (float)t_sym[c][px] + p.mu[pix * p.ld_mu + c];
     }
+}
+
+// ---- 16-byte forms of the two kernels above (same arithmetic per element, same tile): a lane moves four channels of a pixel on
+// the NHWC side and four pixels of a channel on the plane side, so every global access is a dwordx4 and a wave's loads are all in
+// flight before the first use.  Needs 16-byte aligned rows (pointers and pixel strides), HW % 4 == 0 and no mask_src; the
+// launchers fall back to the scalar kernels otherwise.  LDS rows of 68 words keep the plane-side b128 reads aligned.
+#define PC_LS 68
+template <int MODE, bool LIK>
+__global__ __launch_bounds__(256) void gc_prep_vec_kernel(const pc_prep_params p)
+{
+    constexpr int TP = 64, CC = 32;
+    __shared__ __attribute__((aligned(16))) int32_t t_sym[MODE == 0 ? CC : 1][PC_LS];
+    __shared__ __attribute__((aligned(16))) int32_t t_idx[CC][PC_LS];
+    __shared__ __attribute__((aligned(16))) float t_msk[CC][PC_LS];
+    __shared__ __attribute__((aligned(16))) float t_lik[LIK ? CC : 1][PC_LS];
+    __shared__ float s_table[64];
+    const int b = blockIdx.y, p0 = blockIdx.x * TP, tid = threadIdx.x;
+    pc_fill_table64(s_table, p.table, p.ntable);
+    float thr = 0.0f;
+    if (p.mask_mode == 1) thr = p.thr[b];
+    float4 s4[2], mu4[2], y4[2], yb4[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, px = u >> 3, c0 = (u & 7) * 4;
+        s4[k] = mu4[k] = y4[k] = yb4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + px < p.HW) {
+            const int64_t pix = (int64_t)b * p.HW + p0 + px;
+            s4[k] = *reinterpret_cast<const float4*>(p.scale + pix * p.ld_scale + c0);
+            if (MODE == 0) {
+                mu4[k] = *reinterpret_cast<const float4*>(p.mu + pix * p.ld_mu + c0);
+                y4[k] = *reinterpret_cast<const float4*>(p.y + pix * p.ld_y + c0);
+                if (p.ybase) yb4[k] = *reinterpret_cast<const float4*>(p.ybase + pix * p.ld_ybase + c0);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, px = u >> 3, c0 = (u & 7) * 4;
+        if (p0 + px >= p.HW) continue;
+        const int64_t pix = (int64_t)b * p.HW + p0 + px;
+        const float sv[4] = {s4[k].x, s4[k].y, s4[k].z, s4[k].w};
+        const float muv[4] = {mu4[k].x, mu4[k].y, mu4[k].z, mu4[k].w};
+        const float yv[4] = {y4[k].x, y4[k].y, y4[k].z, y4[k].w};
+        const float ybv[4] = {yb4[k].x, yb4[k].y, yb4[k].z, yb4[k].w};
+        float yh[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int c = c0 + j;
+            const float s = sv[j];
+            float m = 1.0f;
+            if (p.mask_mode == 1) m = (s >= thr) ? 1.0f : 0.0f;
+            else if (p.mask_mode == 3) m = 0.0f;
+            const float sm = (p.mask_mode == 0) ? s : s * m;
+            t_idx[c][px] = gc_index64(sm, s_table, p.ntable, p.bound);
+            t_msk[c][px] = m;
+            if (MODE == 0) {
+                const float mu = muv[j];
+                float y = yv[j];
+                if (p.ybase) y = y - ybv[j];
+                float v = y - mu;
+                if (p.mask_mode != 0) v = v * m;
+                const int32_t sym = (int32_t)pc_roundevenf(v);
+                t_sym[c][px] = sym;
+                yh[j] = (float)sym + mu;
+                if (LIK) {
+                    const float values = (p.mask_mode == 0) ? ((float)sym + mu) - mu : (float)sym;
+                    t_lik[c][px] = gc_likelihood(values, sm > p.bound ? sm : p.bound);
+                }
+            }
+        }
+        if (MODE == 0) *reinterpret_cast<float4*>(p.yhat + pix * p.ld_yhat + c0) = make_float4(yh[0], yh[1], yh[2], yh[3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, c = u >> 4, q = (u & 15) * 4;
+        if (p0 + q >= p.HW) continue;
+        const int64_t o = ((int64_t)b * CC + c) * p.HW + p0 + q;
+        const int4 iv = *reinterpret_cast<const int4*>(&t_idx[c][q]);
+        *reinterpret_cast<int4*>(p.idx + o) = iv;
+        if (p.idx8) *reinterpret_cast<uchar4*>(p.idx8 + o) = make_uchar4((uint8_t)iv.x, (uint8_t)iv.y, (uint8_t)iv.z, (uint8_t)iv.w);
+        if (MODE == 0) *reinterpret_cast<int4*>(p.sym + o) = *reinterpret_cast<const int4*>(&t_sym[c][q]);
+        if (p.mask) *reinterpret_cast<float4*>(p.mask + o) = *reinterpret_cast<const float4*>(&t_msk[c][q]);
+        if (LIK) *reinterpret_cast<float4*>(p.lik + (int64_t)b * p.lik_sb + (int64_t)c * p.HW + p0 + q) = *reinterpret_cast<const float4*>(&t_lik[c][q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gc_dequant_vec_kernel(const pc_prep_params p)
+{
+    constexpr int TP = 64, CC = 32;
+    __shared__ __attribute__((aligned(16))) int32_t t_sym[CC][PC_LS];
+    const int b = blockIdx.y, p0 = blockIdx.x * TP, tid = threadIdx.x;
+    float4 mu4[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, c = u >> 4, q = (u & 15) * 4;
+        if (p0 + q < p.HW) *reinterpret_cast<int4*>(&t_sym[c][q]) = *reinterpret_cast<const int4*>(p.sym + ((int64_t)b * CC + c) * p.HW + p0 + q);
+        const int px = u >> 3, c0 = (u & 7) * 4;
+        mu4[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p0 + px < p.HW) mu4[k] = *reinterpret_cast<const float4*>(p.mu + ((int64_t)b * p.HW + p0 + px) * p.ld_mu + c0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int u = tid + 256 * k, px = u >> 3, c0 = (u & 7) * 4;
+        if (p0 + px >= p.HW) continue;
+        const int64_t pix = (int64_t)b * p.HW + p0 + px;
+        *reinterpret_cast<float4*>(p.yhat + pix * p.ld_yhat + c0) =
+            make_float4((float)t_sym[c0][px] + mu4[k].x, (float)t_sym[c0 + 1][px] + mu4[k].y, (float)t_sym[c0 + 2][px] + mu4[k].z,
+                        (float)t_sym[c0 + 3][px] + mu4[k].w);
+    }
+}
+
+static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+static bool prep_vec_ok(const pc_prep_params& p, int mode)   // mode 0 encoder, 1 decoder index, 2 dequantise
+{
+    static const bool off = [] { const char* v = std::getenv("PC_PREP_SCALAR"); return v && std::atoi(v) != 0; }();
+    if (off || (p.HW & 3) || p.mask_src) return false;
+    bool ok = true;
+    if (mode != 2) ok = ok && al16(p.scale) && !(p.ld_scale & 3) && al16(p.idx) && al16(p.mask) && (!p.idx8 || !(reinterpret_cast<uintptr_t>(p.idx8) & 3u));
+    if (mode != 1) ok = ok && al16(p.mu) && !(p.ld_mu & 3) && al16(p.yhat) && !(p.ld_yhat & 3) && al16(p.sym);
+    if (mode == 0) ok = ok && al16(p.y) && !(p.ld_y & 3) && al16(p.ybase) && !(p.ld_ybase & 3) && al16(p.lik) && !(p.lik_sb & 3);
+    return ok;
 }
 
 // EntropyBottleneck: z NHWC [B][HW][C] -> sym [B][C][HW] (= round(z - median_c)), zhat NHWC = float(sym) + median_c
@@ -621,16 +815,16 @@ int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, flo
     const int64_t n = (int64_t)HW * C;
     static const bool single = [] { const char* v = std::getenv("PC_QUANTILE_SINGLE"); return v && std::atoi(v) != 0; }();
     if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
-    else if (n <= 1024 * 32) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
+    else if (n <= PC_QUANTILE_SMALL_N) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else if (single) hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else {
         uint32_t* w = work;
         if (!w && hipMallocAsync(reinterpret_cast<void**>(&w), pc_quantile_work_bytes(B), stream) != hipSuccess) return PC_ERR_HIP;
-        const int G = (int)std::min<int64_t>(64, (n + 16383) / 16384);
-        hipLaunchKernelGGL(quantile_zero_kernel, dim3(B), dim3(256), 0, stream, w);
-        hipLaunchKernelGGL(quantile_hist_kernel, dim3(G, B), dim3(1024), 0, stream, scale, ld, HW, C, sb, w);
-        hipLaunchKernelGGL(quantile_pick_kernel, dim3(B), dim3(256), 0, stream, n, q, w);
-        hipLaunchKernelGGL(quantile_collect_kernel, dim3(G, B), dim3(1024), 0, stream, scale, ld, HW, C, sb, w);
+        const int G = (int)std::min<int64_t>(256, (n + PC_QW_STEP - 1) / PC_QW_STEP);
+        const bool vec = !(C & 3) && !(ld & 3) && !(sb & 3) && !(reinterpret_cast<uintptr_t>(scale) & 15u);
+        hipLaunchKernelGGL(quantile_sample_kernel, dim3(B), dim3(256), 0, stream, scale, ld, HW, C, q, sb, w);
+        if (vec) hipLaunchKernelGGL(quantile_bracket_kernel<true>, dim3(G, B), dim3(256), 0, stream, scale, ld, HW, C, sb, w);
+        else hipLaunchKernelGGL(quantile_bracket_kernel<false>, dim3(G, B), dim3(256), 0, stream, scale, ld, HW, C, sb, w);
         hipLaunchKernelGGL(quantile_final_kernel, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb, (const uint32_t*)w);
         if (!work && hipFreeAsync(w, stream) != hipSuccess) return PC_ERR_HIP;
     }
@@ -641,19 +835,26 @@ size_t pc_quantile_work_bytes(int B) { return (size_t)B * PC_QW_STRIDE * sizeof(
 int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream)
 {
     if (p.C != 32 || p.ntable > 64 || p.ntable < 2) return PC_ERR_ARG;
-    hipLaunchKernelGGL((gc_prep_kernel<0>), dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    const dim3 grid((p.HW + 63) / 64, p.B);
+    if (!prep_vec_ok(p, 0)) hipLaunchKernelGGL((gc_prep_kernel<0>), grid, dim3(256), 0, stream, p);
+    else if (p.lik) hipLaunchKernelGGL((gc_prep_vec_kernel<0, true>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gc_prep_vec_kernel<0, false>), grid, dim3(256), 0, stream, p);
     return PC_LAUNCH_CHECK();
 }
 int pc_prep_dec_index_launch(const pc_prep_params& p, hipStream_t stream)
 {
     if (p.C != 32 || p.ntable > 64 || p.ntable < 2) return PC_ERR_ARG;
-    hipLaunchKernelGGL((gc_prep_kernel<1>), dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    const dim3 grid((p.HW + 63) / 64, p.B);
+    if (!prep_vec_ok(p, 1)) hipLaunchKernelGGL((gc_prep_kernel<1>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((gc_prep_vec_kernel<1, false>), grid, dim3(256), 0, stream, p);
     return PC_LAUNCH_CHECK();
 }
 int pc_prep_dec_dequant_launch(const pc_prep_params& p, hipStream_t stream)
 {
     if (p.C != 32) return PC_ERR_ARG;
-    hipLaunchKernelGGL(gc_dequant_kernel, dim3((p.HW + 63) / 64, p.B), dim3(256), 0, stream, p);
+    const dim3 grid((p.HW + 63) / 64, p.B);
+    if (!prep_vec_ok(p, 2)) hipLaunchKernelGGL(gc_dequant_kernel, grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(gc_dequant_vec_kernel, grid, dim3(256), 0, stream, p);
     return PC_LAUNCH_CHECK();
 }
 int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* med, int32_t* sym, float* zhat, hipStream_t stream)

@@ -185,7 +185,51 @@ def test_quantile_threshold_bit_exact(n_hw, pr):
     assert np.array_equal(got, t)
 
 
-@pytest.mark.parametrize("hw,mode,delta", [(16, 0, 0), (256, 1, 1), (100, 1, 1), (256, 2, 1), (1024, 3, 1)])
+@pytest.mark.parametrize("kind", ["plain", "q0", "q1", "ties_over_capacity", "constant", "nan", "neg_nan", "unaligned_ld", "ragged_2m", "smooth", "two_clusters"])
+def test_quantile_large_image_path(kind):
+    """n > 32768: sample -> bracket -> select (pc_stages.hip).  The sample only steers; the result must be the exact order statistic
+    whatever the data: heavy ties and adversarial layouts take the verified fallback."""
+    L, check = _lib()
+    rng = np.random.default_rng(len(kind))
+    B, hw, ld, pr = 3, 4096, 32, 0.5
+    if kind == "ragged_2m":
+        B, hw = 2, 256 * 255 + 3                               # 2.09 M elements: the bracket kernel loops, last step ragged
+    if kind == "unaligned_ld":
+        ld, hw = 33, 1300                                      # scalar loads
+    scale = (0.6 + 0.7 * rng.standard_normal((B, hw, ld))).astype(np.float32)
+    if kind == "q0":
+        pr = 10.0
+    if kind == "q1":
+        pr = 0.0
+    if kind == "ties_over_capacity":
+        scale[0][rng.random((hw, ld)) < 0.6] = 0.11            # 60 % of the image equals the quantile value: more than the list holds
+        scale[1] = np.round(scale[1] * 2) / 2
+        pr = 6.0
+    if kind == "constant":
+        scale[:] = 0.25
+    if kind == "nan":
+        scale[1, 17, 5] = np.nan
+    if kind == "neg_nan":
+        scale[2, 1000, 31] = np.float32(np.uint32(0xffc00001).view(np.float32))
+    if kind == "smooth":                                       # spatially sorted data: runs of 16 consecutive samples are as correlated as can be
+        scale = np.sort(scale.reshape(B, -1), axis=1).reshape(B, hw, ld)
+        pr = 3.3
+    if kind == "two_clusters":                                 # the quantile sits in the empty gap between two clusters
+        scale[:, : hw // 2] = 1e-3 * rng.random((B, hw // 2, ld)).astype(np.float32)
+        scale[:, hw // 2:] += 100.0
+        pr = 5.0
+    q = np.float32(1.0 - pr * 0.1)
+    want = np.array([lo.quantile(scale[b][:, :32], q) for b in range(B)], np.float32)
+    thr = torch.empty(B, device="cuda", dtype=torch.float32)
+    sd = dev(scale)
+    check(L.pc_mask_quantile_threshold(P(sd), ld, B, hw, 32, q, P(thr), None))
+    torch.cuda.synchronize()
+    got = thr.cpu().numpy()
+    assert np.array_equal(got.view(np.uint32) & 0x7fffffff if "nan" in kind else got.view(np.uint32),
+                          want.view(np.uint32) & 0x7fffffff if "nan" in kind else want.view(np.uint32)), (got, want)
+
+
+@pytest.mark.parametrize("hw,mode,delta", [(16, 0, 0), (256, 1, 1), (100, 1, 1), (256, 2, 1), (1024, 3, 1), (99, 1, 1), (4096 + 36, 1, 0), (61, 0, 1)])
 def test_gc_prep_encode_and_decode_bit_exact(hw, mode, delta):
     from tests.util import tables_npz
     L, check = _lib()

@@ -6,11 +6,12 @@ usage: python tools/stage_rocprof.py <dir with *kernel_trace.csv> <n_images> > p
 
 stage_bench.py calls, in this order: the quantile once, then (1 + 10) times each of: quantile, encoder enhancement prep, encoder base
 prep, decoder index, dequantise.  The kernel trace is cut into those calls by start time; a call of the quantile on a Config-4 slice
-is five kernels (zero / histogram / pick / collect / final), every other call is one kernel."""
+is three kernels (sample / bracket / final), every other call is one kernel; the per-kernel averages are reported too."""
 import csv
 import glob
 import json
 import os
+import re
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,11 +32,11 @@ def main():
     # calls in trace order
     calls, cur = [], None
     for name, ns in ks:
-        zero = "gc_prep_kernel<0>" in name or "gc_prep_kernelILi0" in name
-        one = "gc_prep_kernel<1>" in name or "gc_prep_kernelILi1" in name
+        zero = any(t in name for t in ("gc_prep_kernel<0>", "gc_prep_kernelILi0", "gc_prep_vec_kernel<0", "gc_prep_vec_kernelILi0"))
+        one = any(t in name for t in ("gc_prep_kernel<1>", "gc_prep_kernelILi1", "gc_prep_vec_kernel<1", "gc_prep_vec_kernelILi1"))
         key = "quantile" if "quantile" in name else ("gc_prep_kernel<0>" if zero else ("gc_prep_kernel<1>" if one else "gc_dequant"))
         if key == "quantile":
-            if cur is None or cur[0] != "quantile" or "zero" in name or ("thr_kernel" in name):
+            if cur is None or cur[0] != "quantile" or "sample" in name or ("thr_kernel" in name):
                 cur = ["quantile", 0, 0]
                 calls.append(cur)
             cur[1] += ns; cur[2] += 1
@@ -50,10 +51,16 @@ def main():
         out[label] = {"avg_us_per_call": round(t * 1e6, 2), "kernels_per_call": seg[1][2], "algorithmic_bytes_per_element": bpe,
                       "GB_per_s": round(n * bpe / t / 1e9, 1), "frac_of_8TBps": round(n * bpe / t / 8e12, 4)}
         pos += 11
+    per_kernel = {}
+    for name, ns in ks:
+        m = re.search(r"(\w+kernel\w*(<[^>]*>)?)", name)
+        a = per_kernel.setdefault(m.group(1) if m else name, [0, 0])
+        a[0] += ns; a[1] += 1
+    per_kernel = {k: {"calls": v[1], "avg_us": round(v[0] / v[1] * 1e-3, 2)} for k, v in per_kernel.items()}
     from bench import source_hash
     print(json.dumps({"source": f"rocprofv3 --kernel-trace of `python3 tools/stage_bench.py {B}` on one MI355X: one enhancement slice of {B} images of "
                                 "1024x1024 (latent 64x64 x 32 channels); kernel durations from the trace, folded by tools/stage_rocprof.py",
-                      "elements": n, "stages": out, "source_hash": source_hash()}, indent=1))
+                      "elements": n, "stages": out, "kernels": per_kernel, "source_hash": source_hash()}, indent=1))
 
 
 if __name__ == "__main__":
