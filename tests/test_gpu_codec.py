@@ -9,6 +9,7 @@
 """
 import hashlib
 import math
+import os
 
 import numpy as np
 import pytest
@@ -458,6 +459,55 @@ def test_4k_frame_two_levels_properties():
     bits = float(-torch.log2(fwd["likelihoods"]["y"].double()).sum() - torch.log2(fwd["likelihoods"]["z"].double()).sum())
     coded = 8 * (nbytes[1] + len(datas[1]["strings"][1][0]))
     assert 0.9 * bits <= coded <= 1.1 * bits
+
+
+def test_config5_4k_frame_eight_levels_and_gather():
+    """BASELINE Config 5 on one rank: one 3840x2160 frame (padded to 3840x2176), EIGHT progressive levels through the shared-base
+    path, every level decoded, then the bitstream gather of bench.py over the process group (world size 1 here: RCCL on the GPU
+    box; the 8-rank form of the same code runs over gloo in tests/test_parallel.py).  Properties: each level's strings equal the
+    per-level compress() call's; byte counts grow with the level; the mask shares are the requested quantiles (the multi-block
+    quantile path: 32 x 136 x 240 = 1.04 M keys per slice); every level decodes into [0, 1]; the gathered strings are the local ones."""
+    import torch.distributed as dist
+    from progressivecodec_amd.harness import compute_padding as cp
+    from progressivecodec_amd.parallel import gather_bitstreams
+    net = gpu_codec()
+    g = torch.Generator().manual_seed(55)
+    lo_res = torch.rand(1, 3, 270, 480, generator=g)
+    x = (F.interpolate(lo_res, size=(2160, 3840), mode="bilinear", align_corners=False) + 0.03 * torch.randn(1, 3, 2160, 3840, generator=g)).clamp(0, 1)
+    pad, unpad = cp(2160, 3840)
+    xp = F.pad(x, pad).cuda()
+    levels = [0.05, 0.25, 0.5, 1, 2, 3, 5, 10]
+    datas = net.compress_levels(xp, levels, "point-based-std")
+    assert len(datas) == 8
+    for lv in (0, 4, 7):
+        one = net.compress(xp, levels[lv], "point-based-std")
+        assert datas[lv]["strings"] == one["strings"]
+    nbytes = [sum(len(s[0]) for s in d["strings"][0]) for d in datas]
+    assert all(a < b for a, b in zip(nbytes, nbytes[1:])), nbytes
+    k = 32 * 136 * 240
+    for lv, q in enumerate(levels):
+        for m in datas[lv]["masks"]:
+            assert abs(int(m.sum().item()) - min(1.0, q * 0.1) * k) <= 8
+    outs = net.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], levels, "point-based-std")
+    psnr = []
+    for o in outs:
+        xh = F.pad(o["x_hat"], unpad)
+        assert tuple(xh.shape) == (1, 3, 2160, 3840) and 0.0 <= xh.min().item() and xh.max().item() <= 1.0
+        psnr.append(float(-10 * torch.log10(((xh.cpu() - x) ** 2).mean())))
+    fwd = net.forward_single_quality(xp, levels[-1], "point-based-std")
+    assert torch.equal(outs[-1]["x_hat"], fwd["x_hat"])
+    print(f"Config 5 frame: y bytes per level {nbytes}, PSNR per level (synthetic weights) {[round(p, 2) for p in psnr]}")
+    own = not dist.is_initialized()
+    if own:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29561")
+        dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        for d in (datas[0], datas[7]):
+            assert gather_bitstreams(d["strings"][0]) == d["strings"][0]
+            assert gather_bitstreams([d["strings"][1]]) == [d["strings"][1]]
+    finally:
+        if own:
+            dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("idx", [0, 1, 2])
