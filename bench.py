@@ -132,12 +132,14 @@ def newest_profile(pattern, src):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="images per GPU (Config 2: 32)")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap", type=int, default=1, help="1 (default): the decode of step i runs beside the encode of step i+1 -- an encoder and a "
+                    "decoder codec object on their own streams and host threads; 0: compress() then decompress(), one after the other")
     ap.add_argument("--cpu-images", type=int, default=32, help="images of rank 0's batch the CPU port codes (x2 repetitions)")
     args = ap.parse_args()
 
@@ -188,16 +190,61 @@ def main():
         if world > 1:
             dist.barrier()
 
+    net_dec = None
+    if args.overlap:
+        # a second codec object (own weights copy and workspaces) decodes step i on its own stream and host thread while the first
+        # one encodes step i+1: every step is still one compress() and one decompress() of the same batch, all inside the timed region
+        import queue
+        import threading
+        net_dec = ChannelProgresssiveWACNN(device=str(dev))
+        net_dec.load_state_dict(sd)
+        net_dec.update()
+        s_enc, s_dec = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+
+    def run_steps(n):
+        if not args.overlap:
+            res = None
+            for _ in range(n):
+                res = step()
+            return res
+        qu, box = queue.Queue(maxsize=2), {}
+
+        def decoder():
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(s_dec):
+                    while True:
+                        o = qu.get()
+                        if o is None:
+                            return
+                        box["dec"] = net_dec.decompress(o["strings"], o["shape"], q, MASK_POL)
+            except BaseException as e:                       # surfaced by the main thread
+                box["err"] = e
+                while qu.get() is not None:
+                    pass
+        th = threading.Thread(target=decoder)
+        th.start()
+        o = None
+        with torch.cuda.stream(s_enc):
+            for _ in range(n):
+                o = net.compress(x, q, MASK_POL)
+                qu.put(o)
+        qu.put(None)
+        th.join()
+        if "err" in box:
+            raise box["err"]
+        s_enc.synchronize(); s_dec.synchronize()
+        return o, box["dec"]
+
     log(f"weights loaded, tables built; batch {B}x3x{S}x{S} resident; warmup x{args.warmup}")
     for i in range(args.warmup):
         tw = time.perf_counter()
-        out, dec = step()
+        out, dec = run_steps(1)
         torch.cuda.synchronize(dev)
         log(f"warmup step {i}: {time.perf_counter() - tw:.3f} s")
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out, dec = step()
+    out, dec = run_steps(args.steps)
     torch.cuda.synchronize(dev)
     t1 = time.perf_counter()
     elapsed = t1 - t0
@@ -273,7 +320,11 @@ def main():
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"Config 2: batch {B} x {S}x{S} random crops per GPU, quality {q}, mask_pol {MASK_POL}, "
                                "synthetic seeded weights (canonical ChannelProgresssiveWACNN)",
-                   "images_per_gpu": B, "height": S, "width": S, "quality": q, "sharding": f"images x {world} ranks"},
+                   "images_per_gpu": B, "height": S, "width": S, "quality": q, "sharding": f"images x {world} ranks",
+                   "step_schedule": ("every step = compress() + decompress() of the batch, all inside the timed region; the decode of step i "
+                                     "overlaps the encode of step i+1 (encoder and decoder codec objects, two streams, two host threads)")
+                   if args.overlap else "every step = compress() then decompress(), strictly one after the other"},
+        "serial_step_ms": round(1e3 * (tc - ta), 2),
         "enc_ms": round(1e3 * (tb - ta), 2), "dec_ms": round(1e3 * (tc - tb), 2),
         "bpp": round(bpp, 4), "psnr_db": round(psnr, 4), "coded_bytes_job": total_bytes,
         "path_frac_of_f32_mfma_peak": round(value * 1e6 * MFLOP_PER_PX_Q * 1e6 / world / (PEAK_F32_MFMA * 1e12), 4),
