@@ -303,7 +303,7 @@ __device__ unsigned long long pc_dbg_stamps[8192][16];
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : ((r >> 1) & 7); }
+template <int KQ> __device__ __forceinline__ int pc_swz(int r) { return KQ == 16 ? (r & 15) : (KQ == 4 ? ((r >> 2) & 3) : ((r >> 1) & 7)); }
 
 template <int N> __device__ __forceinline__ void pc_wait_vm()
 {
@@ -1378,7 +1378,8 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             // accumulators per wave, 25 % less L2->LDS traffic, half the DMA / ds_read instructions per MFMA) with two stages once
             // there are >= 6 of the smaller blocks per CU anyway (the high-resolution layers of g_a / g_s: +3..6 %).
             const long nb64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
-            int tm = tm_env ? tm_env : (nb64 >= 1536 ? 2 : 1), tn = tn_env ? tn_env : 1;
+            static const long tm_thr = [] { const char* v = std::getenv("PC_CONV_TM_THR"); return v ? std::atol(v) : 1536L; }();
+            int tm = tm_env ? tm_env : (nb64 >= tm_thr ? 2 : 1), tn = tn_env ? tn_env : 1;
             const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
             const int ab = (p.dbg & 64) ? 0 : (p.dbg & 15);                   // ablation builds of the 64x64 three-stage instantiation
             if (p.square) e = launch_uni<32, 2, 1, 1, true>(p, stream);
@@ -1391,6 +1392,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             else if (ab == 0 && (p.dbg & 16) && !(p.dbg & 64)) e = launch_uni<32, 3, 1, 1, false, 16>(p, stream);
             else if ((p.dbg & 64) && (p.dbg & 8)) e = launch_uni<32, 3, 1, 1, false, 74>(p, stream);
             else if (p.dbg & 64) e = launch_uni<32, 3, 1, 1, false, 64>(p, stream);
+            else if (bk == 16 && Su >= 3) e = launch_uni<16, 4, 1, 1>(p, stream);
 #define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
             PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
             PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2) PC_UNI_CASE(4, 1, 1)
