@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpcodec.so")
+LIB_PATH = os.environ.get("PC_LIB") or os.path.join(_HERE, "libpcodec.so")   # PC_LIB: another build of the same library (same-box A/B)
 
 PC_OK = 0
 ERRORS = {-1: "PC_ERR_ARG", -2: "PC_ERR_INDEX", -3: "PC_ERR_BUFFER", -4: "PC_ERR_TRUNCATED", -5: "PC_ERR_CDF",

@@ -905,52 +905,79 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
         b_addr[g] = smem_lds + (uint32_t)(A_PIECES + bn * KQ + ((2 * g + half) ^ b_swz)) * 16u;
     }
     constexpr bool IMM_STAGE = (S - 1) * STAGE * 16 + (TM > TN ? TM : TN) * 32 * KQ * 16 < 65536;   // ds_read's offset field is 16 bits
-    // one chunk: NL live column tiles; ISSUE: place the NI pieces of the chunk being fetched behind MFMAs; ST: the stage being read
-    auto chunk = [&](auto nl_tag, auto issue_tag, auto st_tag) {
+    // The K loop is software-pipelined across the chunk boundary: the barrier that opens chunk c+1 (its pieces have landed, every wave
+    // is done reading chunk c) sits in front of the LAST k-group of chunk c, whose operands are already in registers, and the first
+    // operand reads of chunk c+1 are issued right behind it -- their LDS latency runs under that group's MFMAs instead of draining
+    // the wave's MFMA chain at every chunk start (a workgroup alone on its CU -- the N <= 64 layers, the last round of every launch --
+    // ran at 62 % of its chain's pace with the barrier at the chunk start; tools/conv_timeline.py).  All NI pieces of the chunk being
+    // fetched are placed behind the MFMAs of the first NG-1 groups, so the vmcnt in front of that barrier is the same constant as
+    // before.  NEXT: 0 = last chunk, 1 = another main step follows, 2 = a tail chunk follows (`allowed` chunks may stay in flight).
+    f32x4 va[2][TM], vb[2][TN];
+    if (DBG & 8) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) va[h2][i] = f32x4{1.f, 2.f, 3.f, 4.f};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) vb[h2][j] = f32x4{1.f, 2.f, 3.f, 4.f};
+        }
+    }
+    auto reads = [&](auto nl_tag, auto st_tag, auto g_tag) {
+        constexpr int NL = decltype(nl_tag)::value, ST = decltype(st_tag)::value, g = decltype(g_tag)::value;
+        if ((DBG & 8) || NL == 0) return;
+        const uint32_t st_off = IMM_STAGE ? 0u : (uint32_t)(ST * STAGE * 16);
+        constexpr int IMM = IMM_STAGE ? ST * STAGE * 16 : 0;
+        const uint32_t aa = a_addr[g] + st_off, ba = b_addr[g] + st_off;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { f32x4 t; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(aa), "n"(IMM + i * 32 * KQ * 16)); va[g & 1][i] = t; }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) { f32x4 t; asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(t) : "v"(ba), "n"(IMM + j * 32 * KQ * 16)); vb[g & 1][j] = t; }
+    };
+    // The operands of a chunk's first k-group are in registers before control leaves the straight-line code that issued their reads:
+    // hipcc may copy or re-allocate the buffers at a block boundary (loop back-edge, run boundary), which must not happen to a
+    // register an LDS read is still writing.
+    auto land0 = [&]() {
+        if (DBG & 8) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) { f32x4 t = va[0][i]; asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t)); va[0][i] = t; }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) { f32x4 t = vb[0][j]; asm volatile("" : "+v"(t)); vb[0][j] = t; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // open chunk `next`: its pieces landed (this wave's; the barrier makes that true of every wave's), every wave done with the chunk before
+    auto open_main = [&]() { pc_wait_vm<NI * (S - 2)>(); __builtin_amdgcn_s_barrier(); };
+    auto open_tail = [&](int allowed) { pc_wait_chunks<NI, S - 2>(allowed); __builtin_amdgcn_s_barrier(); };
+    auto chunk = [&](auto nl_tag, auto issue_tag, auto st_tag, auto next_tag, int allowed) {
         constexpr int NL = decltype(nl_tag)::value;
         constexpr bool ISSUE = decltype(issue_tag)::value;
-        constexpr int ST = decltype(st_tag)::value, ST_I = (ST + S - 1) % S;   // chunk c in stage ST; chunk c + S - 1 goes where c - 1 was
-        constexpr int NS = NG * 4 * TM * (NL > 0 ? NL : 1);           // MFMA slots of this variant
+        constexpr int NEXT = decltype(next_tag)::value;
+        constexpr int ST = decltype(st_tag)::value, ST_I = (ST + S - 1) % S, ST_N = (ST + 1) % S;   // chunk c in stage ST; chunk c + S - 1 goes where c - 1 was
+        constexpr int NSE = (NG > 1 ? NG - 1 : 1) * 4 * TM * (NL > 0 ? NL : 1);   // MFMA slots that may carry a piece: those of the first NG-1 groups
+        auto handover = [&]() {                                           // in front of the last group's MFMAs
+            if (NEXT == 0) return;
+            if (NEXT == 1) open_main(); else open_tail(allowed);
+            reads(nl_tag, std::integral_constant<int, ST_N>{}, std::integral_constant<int, 0>{});
+        };
         if (ISSUE && (NL == 0 || (DBG & 16))) {                       // no MFMAs to hide behind: all pieces now
 #pragma unroll
             for (int q = 0; q < NI; ++q) piece(q, ST_I);
         }
-        if (NL == 0) return;                                          // a wave with no live column only loads its share
+        if (NL == 0) { handover(); return; }                          // a wave with no live column only loads its share
         constexpr bool interleave = ISSUE && !(DBG & 16);
-        const uint32_t st_off = IMM_STAGE ? 0u : (uint32_t)(ST * STAGE * 16);
-        constexpr int IMM = IMM_STAGE ? ST * STAGE * 16 : 0;
-        f32x4 va[2][TM], vb[2][TN];
-        if (DBG & 8) {
+        auto group = [&](auto g_tag) {
+            constexpr int g = decltype(g_tag)::value;
+            if constexpr (g + 1 < NG) {
+                reads(nl_tag, st_tag, std::integral_constant<int, g + 1>{});
+                // wait for group g's operands only (the TM + NL reads of group g+1 just issued stay in flight); the operands are tied
+                // to the wait so that no MFMA using them can be scheduled above it
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
+                for (int i = 0; i < TM; ++i) { if (!(DBG & 8)) { f32x4 t = va[g & 1][i]; asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(t) : "n"(TM + NL)); va[g & 1][i] = t; } }
+            } else {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) va[h2][i] = f32x4{1.f, 2.f, 3.f, 4.f};
-#pragma unroll
-                for (int j = 0; j < TN; ++j) vb[h2][j] = f32x4{1.f, 2.f, 3.f, 4.f};
-            }
-        }
-        auto reads = [&](int g) {
-            if (DBG & 8) return;
-            const uint32_t aa = a_addr[g] + st_off, ba = b_addr[g] + st_off;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(va[g & 1][i]) : "v"(aa), "n"(IMM + i * 32 * KQ * 16));
-#pragma unroll
-            for (int j = 0; j < NL; ++j) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(vb[g & 1][j]) : "v"(ba), "n"(IMM + j * 32 * KQ * 16));
-        };
-        reads(0);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) reads(g + 1);
-            // wait for group g's operands only (the TM + NL reads of group g+1 just issued stay in flight); the operands are tied to
-            // the wait so that no MFMA using them can be scheduled above it
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if (DBG & 8) continue;
-                if (g + 1 < NG) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(va[g & 1][i]) : "n"(TM + NL));
-                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(va[g & 1][i]));
+                for (int i = 0; i < TM; ++i) { if (!(DBG & 8)) { f32x4 t = va[g & 1][i]; asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t)); va[g & 1][i] = t; } }
             }
 #pragma unroll
-            for (int j = 0; j < NL; ++j) asm volatile("" : "+v"(vb[g & 1][j]));
+            for (int j = 0; j < NL; ++j) { f32x4 t = vb[g & 1][j]; asm volatile("" : "+v"(t)); vb[g & 1][j] = t; }
             __builtin_amdgcn_sched_barrier(0);
             float xa[TM][4], xb[TN][4];
 #pragma unroll
@@ -961,6 +988,11 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             }
 #pragma unroll
             for (int j = 0; j < NL; ++j) { const f32x4 y = vb[g & 1][j]; xb[j][0] = y.x; xb[j][1] = y.y; xb[j][2] = y.z; xb[j][3] = y.w; }
+            if constexpr (g + 1 == NG) {                              // this wave's reads of the chunk are complete (lgkmcnt(0) above)
+                __builtin_amdgcn_sched_barrier(0);
+                handover();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -968,15 +1000,21 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
 #pragma unroll
                     for (int j = 0; j < NL; ++j) {
                         if (!(DBG & 1)) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[i][s], xb[j][s], acc[i][j], 0, 0, 0);
-                        if (interleave) {
+                        if (interleave && (g + 1 < NG || NG == 1)) {
                             const int slot_ix = ((g * 4 + s) * TM + i) * NL + j;      // compile-time after unrolling
 #pragma unroll
                             for (int q = 0; q < NI; ++q)
-                                if ((q * NS) / NI == slot_ix) { __builtin_amdgcn_sched_barrier(0); piece(q, ST_I); __builtin_amdgcn_sched_barrier(0); }
+                                if ((q * NSE) / NI == slot_ix) { __builtin_amdgcn_sched_barrier(0); piece(q, ST_I); __builtin_amdgcn_sched_barrier(0); }
                         }
                     }
             __builtin_amdgcn_sched_barrier(0);
-        }
+        };
+        group(std::integral_constant<int, 0>{});
+        if constexpr (NG > 1) group(std::integral_constant<int, 1>{});
+        if constexpr (NG > 2) group(std::integral_constant<int, 2>{});
+        if constexpr (NG > 3) group(std::integral_constant<int, 3>{});
+        static_assert(NG <= 4, "k-groups per chunk");
+        if (NEXT != 0) land0();                                       // the next chunk's first operands, read under the last group's MFMAs
     };
     // The chunk loop is unrolled by S so that the stage is a compile-time constant of each body (immediate LDS offsets, no address
     // VALU) while the accumulators stay in ONE register set along a straight-line path (a per-chunk switch over the stage made hipcc
@@ -990,40 +1028,44 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             st_i = st_i + 1 == S ? 0 : st_i + 1;
         }
         const int n_main = nchunks - (S - 1) > 0 ? nchunks - (S - 1) : 0;
-        auto step = [&](auto st_tag) {                                // chunk c < n_main: fetch chunk c + S - 1 behind its MFMAs
-            pc_wait_vm<NI * (S - 2)>();
-            __builtin_amdgcn_s_barrier();
-            chunk(nl_tag, std::true_type{}, st_tag);
-            advance();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        };
-        auto tail = [&](auto st_tag, int left_after) {                // one of the last S-1 chunks: nothing left to fetch
-            pc_wait_chunks<NI, S - 2>(left_after);
-            __builtin_amdgcn_s_barrier();
-            chunk(nl_tag, std::false_type{}, st_tag);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // open chunk 0 and start its first operand reads
+        if (n_main > 0) open_main(); else open_tail(nchunks - 1);
+        reads(nl_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        land0();
+        // chunk c; what follows it decides how the next one is opened from inside its last group
+        auto run_chunk = [&](auto st_tag, int c) {
+            const int after = nchunks - 1 - c;                            // chunks behind this one
+            if (c < n_main) {                                            // fetch chunk c + S - 1 behind its MFMAs
+                if (c + 1 < n_main) chunk(nl_tag, std::true_type{}, st_tag, std::integral_constant<int, 1>{}, 0);
+                else if (after > 0) chunk(nl_tag, std::true_type{}, st_tag, std::integral_constant<int, 2>{}, after - 1);
+                else chunk(nl_tag, std::true_type{}, st_tag, std::integral_constant<int, 0>{}, 0);
+                advance();
+            } else {                                                     // one of the last S-1 chunks: nothing left to fetch
+                if (after > 0) chunk(nl_tag, std::false_type{}, st_tag, std::integral_constant<int, 2>{}, after - 1);
+                else chunk(nl_tag, std::false_type{}, st_tag, std::integral_constant<int, 0>{}, 0);
+            }
         };
         int c = 0;
-        for (; c + S <= n_main; c += S) {
+        for (; c + S <= n_main - 1; c += S) {                            // full rounds of main steps, each followed by another main step
+            auto step = [&](auto st_tag) { chunk(nl_tag, std::true_type{}, st_tag, std::integral_constant<int, 1>{}, 0); advance(); };
             step(std::integral_constant<int, 0>{});
             step(std::integral_constant<int, 1 % S>{});
             if constexpr (S >= 3) step(std::integral_constant<int, 2 % S>{});
             if constexpr (S >= 4) step(std::integral_constant<int, 3 % S>{});
         }
-        // what is left (fewer than S main chunks, then the S-1 tail chunks): c is a multiple of S, so leftover t sits in stage t % S
+        // what is left (at most S main chunks, then the S-1 tail chunks): c is a multiple of S, so leftover t sits in stage t % S
         auto rest = [&](auto t_tag) {
             constexpr int t = decltype(t_tag)::value;
-            if (c + t < nchunks) {
-                if (c + t < n_main) step(std::integral_constant<int, t % S>{});
-                else tail(std::integral_constant<int, t % S>{}, nchunks - 1 - (c + t));
-            }
+            if (c + t < nchunks) run_chunk(std::integral_constant<int, t % S>{}, c + t);
         };
         rest(std::integral_constant<int, 0>{});
         rest(std::integral_constant<int, 1>{});
-        if constexpr (2 * S - 2 > 2) rest(std::integral_constant<int, 2>{});
-        if constexpr (2 * S - 2 > 3) rest(std::integral_constant<int, 3>{});
-        if constexpr (2 * S - 2 > 4) rest(std::integral_constant<int, 4>{});
-        if constexpr (2 * S - 2 > 5) rest(std::integral_constant<int, 5>{});
+        rest(std::integral_constant<int, 2>{});
+        if constexpr (2 * S - 1 > 3) rest(std::integral_constant<int, 3>{});
+        if constexpr (2 * S - 1 > 4) rest(std::integral_constant<int, 4>{});
+        if constexpr (2 * S - 1 > 5) rest(std::integral_constant<int, 5>{});
+        if constexpr (2 * S - 1 > 6) rest(std::integral_constant<int, 6>{});
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     if (DBG & 64) tl[1] = __builtin_amdgcn_s_memrealtime();
     if (nlive == TN) kloop(std::integral_constant<int, TN>{});
