@@ -1052,6 +1052,8 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             step(std::integral_constant<int, 1 % S>{});
             if constexpr (S >= 3) step(std::integral_constant<int, 2 % S>{});
             if constexpr (S >= 4) step(std::integral_constant<int, 3 % S>{});
+            if constexpr (S >= 5) step(std::integral_constant<int, 4 % S>{});
+            if constexpr (S >= 6) step(std::integral_constant<int, 5 % S>{});
         }
         // what is left (at most S main chunks, then the S-1 tail chunks): c is a multiple of S, so leftover t sits in stage t % S
         auto rest = [&](auto t_tag) {
@@ -1065,6 +1067,11 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
         if constexpr (2 * S - 1 > 4) rest(std::integral_constant<int, 4>{});
         if constexpr (2 * S - 1 > 5) rest(std::integral_constant<int, 5>{});
         if constexpr (2 * S - 1 > 6) rest(std::integral_constant<int, 6>{});
+        if constexpr (2 * S - 1 > 7) rest(std::integral_constant<int, 7>{});
+        if constexpr (2 * S - 1 > 8) rest(std::integral_constant<int, 8>{});
+        if constexpr (2 * S - 1 > 9) rest(std::integral_constant<int, 9>{});
+        if constexpr (2 * S - 1 > 10) rest(std::integral_constant<int, 10>{});
+        static_assert(S <= 6, "stages");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     };
     if (DBG & 64) tl[1] = __builtin_amdgcn_s_memrealtime();
@@ -1086,7 +1093,9 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     // ---- epilogue, tile by tile
     if (nlive == 0) { stamp_out(); return; }
     const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
-    float* tile = reinterpret_cast<float*>(smem + wave * 512);        // 2 x 4 KB per wave (S * STAGE >= 2048 float4)
+    // aux tiles of the tile being finished, 4 KB each: aux0 alone -> 4 KB per wave, aux0 + aux1 -> 8 KB per wave (launch_uni sizes the
+    // allocation for that when the stages are smaller)
+    float* tile = reinterpret_cast<float*>(smem) + wave * (u1 ? 2048 : 1024);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1310,7 +1319,11 @@ hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
     constexpr int BM = 64 * TM, BN = 64 * TN;
     int tmax = 0;
     for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
-    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * 2 * sizeof(pc_run);
+    const bool u1 = p.epi == PC_EPI_GATE || p.epi == PC_EPI_LRP_ADD;                         // epilogue_uses_aux1
+    const bool u0 = u1 || p.epi == PC_EPI_RES_GELU || p.epi == PC_EPI_RES || p.epi == PC_EPI_GDN || p.epi == PC_EPI_IGDN || p.epi == PC_EPI_LRP ||
+                    p.epi == PC_EPI_LEAKY_RES;                                                 // epilogue_uses_aux0
+    const size_t stage_bytes = (size_t)S * (BM + BN) * (BK / 4) * 16, epi_bytes = !p.dense_out ? 0 : (u1 ? 32768 : (u0 ? 16384 : 0));
+    const size_t lds = std::max(stage_bytes, epi_bytes) + (size_t)tmax * p.nseg * 2 * sizeof(pc_run);
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);
     auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ, DBG>;
@@ -1420,6 +1433,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             // accumulators per wave, 25 % less L2->LDS traffic, half the DMA / ds_read instructions per MFMA) with two stages once
             // there are >= 6 of the smaller blocks per CU anyway (the high-resolution layers of g_a / g_s: +3..6 %).
             const long nb64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
+            static const int policy = [] { const char* v = std::getenv("PC_CONV_POLICY"); return v ? std::atoi(v) : 1; }();
             static const long tm_thr = [] { const char* v = std::getenv("PC_CONV_TM_THR"); return v ? std::atol(v) : 1536L; }();
             int tm = tm_env ? tm_env : (nb64 >= tm_thr ? 2 : 1), tn = tn_env ? tn_env : 1;
             const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
@@ -1434,7 +1448,13 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             else if (ab == 0 && (p.dbg & 16) && !(p.dbg & 64)) e = launch_uni<32, 3, 1, 1, false, 16>(p, stream);
             else if ((p.dbg & 64) && (p.dbg & 8)) e = launch_uni<32, 3, 1, 1, false, 74>(p, stream);
             else if (p.dbg & 64) e = launch_uni<32, 3, 1, 1, false, 64>(p, stream);
-            else if (bk == 16 && Su >= 3) e = launch_uni<16, 4, 1, 1>(p, stream);
+            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 2) e = launch_uni<16, 2, 1, 1>(p, stream);
+            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 3) e = launch_uni<16, 3, 1, 1>(p, stream);
+            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 5) e = launch_uni<16, 5, 1, 1>(p, stream);
+            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 6) e = launch_uni<16, 6, 1, 1>(p, stream);
+            else if (bk == 16 && tm == 1 && tn == 1) e = launch_uni<16, 4, 1, 1>(p, stream);
+            else if (policy == 1 && !s_env && !tm_env && !tn_env) e = launch_uni<16, 3, 1, 1>(p, stream);
+            else if (policy == 2 && !s_env && !tm_env && !tn_env && tm == 1) e = launch_uni<16, 3, 1, 1>(p, stream);
 #define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
             PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
             PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2) PC_UNI_CASE(4, 1, 1)
