@@ -153,6 +153,12 @@ def main():
         print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): the two must agree", file=sys.stderr, flush=True)
         sys.exit(2)
     os.environ.setdefault("LOCAL_WORLD_SIZE", str(world))    # one node: the host entropy-coding pool takes 1 / world of the CPUs, pinned
+    if args.overlap:
+        # The two codec objects keep ~20 HIP streams busy; ROCm maps them onto GPU_MAX_HW_QUEUES hardware queues (default 4), and two
+        # streams that share a queue run one after the other.  With 4 or 8 queues the overlapped run is bimodal (39 or 44 MP/s by
+        # how the streams happen to fall); from 12 up every critical stream has a queue of its own (profiles/r02_n_hw_queues.log).
+        # Read by the HIP runtime when it initialises: set before anything touches the GPU.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
     import torch
     if world > 1:
@@ -323,7 +329,8 @@ def main():
                    "images_per_gpu": B, "height": S, "width": S, "quality": q, "sharding": f"images x {world} ranks",
                    "step_schedule": ("every step = compress() + decompress() of the batch, all inside the timed region; the decode of step i "
                                      "overlaps the encode of step i+1 (encoder and decoder codec objects, two streams, two host threads)")
-                   if args.overlap else "every step = compress() then decompress(), strictly one after the other"},
+                   if args.overlap else "every step = compress() then decompress(), strictly one after the other",
+                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
         "serial_step_ms": round(1e3 * (tc - ta), 2),
         "enc_ms": round(1e3 * (tb - ta), 2), "dec_ms": round(1e3 * (tc - tb), 2),
         "bpp": round(bpp, 4), "psnr_db": round(psnr, 4), "coded_bytes_job": total_bytes,

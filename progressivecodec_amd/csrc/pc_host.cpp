@@ -226,16 +226,36 @@ extern "C" int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, u
 // ------------------------------------------------------------------------------------------
 namespace pc {
 
+// Several callers may be inside parallel_for at once (the lanes of a decoder; an encoder and a decoder object of the same process):
+// every call is a job in a shared list, the workers take items from whichever job has the fewest left (a decoder's 32 short streams
+// are not queued behind an encoder's 640), the caller works on its own job and returns when its last item is done.
 struct ThreadPool::Impl {
+    struct Job {
+        const std::function<void(size_t)>* fn;
+        size_t n, next = 0;                 // next: guarded by mu
+        std::atomic<size_t> done{0};
+    };
     std::vector<std::thread> workers;
-    std::mutex mu, call_mu;   // call_mu serialises concurrent parallel_for callers (decoder lanes)
+    std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    const std::function<void(size_t)>* fn = nullptr;
-    size_t n_items = 0;
-    std::atomic<size_t> next{0};
-    size_t active = 0;
-    uint64_t generation = 0;
+    std::vector<Job*> jobs;                 // jobs that still have unclaimed items
     bool stop = false;
+
+    // claim one item of the job with the fewest unclaimed items (mu held); false: nothing to do
+    bool claim(Job*& job, size_t& item)
+    {
+        Job* best = nullptr;
+        for (Job* j : jobs) if (!best || j->n - j->next < best->n - best->next) best = j;
+        if (!best) return false;
+        job = best; item = best->next++;
+        if (best->next == best->n) jobs.erase(std::find(jobs.begin(), jobs.end(), best));
+        return true;
+    }
+    void finish(Job* job)                   // after running one item; `job` may be gone as soon as done reaches n
+    {
+        const size_t n = job->n;
+        if (job->done.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { std::lock_guard<std::mutex> lk(mu); cv_done.notify_all(); }
+    }
 };
 
 // CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota.  On a multi-GPU node every rank (one per GPU) has
@@ -307,18 +327,17 @@ ThreadPool::ThreadPool(int n_threads) : impl_(new Impl)
                 (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
             }
             Impl& s = *impl_;
-            uint64_t seen = 0;
             for (;;) {
-                std::unique_lock<std::mutex> lk(s.mu);
-                s.cv_work.wait(lk, [&] { return s.stop || s.generation != seen; });
-                if (s.stop) return;
-                seen = s.generation;
-                const auto* fn = s.fn;
-                const size_t n = s.n_items;
-                lk.unlock();
-                for (;;) { const size_t i = s.next.fetch_add(1); if (i >= n) break; (*fn)(i); }
-                lk.lock();
-                if (--s.active == 0) s.cv_done.notify_all();
+                Impl::Job* job = nullptr;
+                size_t item = 0;
+                {
+                    std::unique_lock<std::mutex> lk(s.mu);
+                    s.cv_work.wait(lk, [&] { return s.stop || !s.jobs.empty(); });
+                    if (s.stop) return;
+                    if (!s.claim(job, item)) continue;
+                }
+                (*job->fn)(item);
+                s.finish(job);
             }
         });
     }
@@ -337,15 +356,23 @@ void ThreadPool::parallel_for(size_t n, const std::function<void(size_t)>& fn)
     Impl& s = *impl_;
     if (n == 0) return;
     if (s.workers.empty() || n == 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::lock_guard<std::mutex> call_lk(s.call_mu);
-    {
-        std::lock_guard<std::mutex> lk(s.mu);
-        s.fn = &fn; s.n_items = n; s.next = 0; s.active = s.workers.size(); ++s.generation;
-    }
+    Impl::Job job;
+    job.fn = &fn; job.n = n;
+    { std::lock_guard<std::mutex> lk(s.mu); s.jobs.push_back(&job); }
     s.cv_work.notify_all();
-    for (;;) { const size_t i = s.next.fetch_add(1); if (i >= n) break; fn(i); }
+    for (;;) {                                             // the caller works on its own job only
+        size_t item;
+        {
+            std::lock_guard<std::mutex> lk(s.mu);
+            if (job.next >= job.n) break;
+            item = job.next++;
+            if (job.next == job.n) s.jobs.erase(std::find(s.jobs.begin(), s.jobs.end(), &job));
+        }
+        fn(item);
+        job.done.fetch_add(1, std::memory_order_acq_rel);
+    }
     std::unique_lock<std::mutex> lk(s.mu);
-    s.cv_done.wait(lk, [&] { return s.active == 0; });
+    s.cv_done.wait(lk, [&] { return job.done.load(std::memory_order_acquire) == n; });
 }
 
 ThreadPool& default_pool()

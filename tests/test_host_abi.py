@@ -87,6 +87,47 @@ def test_rans_matches_oracle_on_random_streams_and_batches():
     assert L.pc_rans_decode_batch_u8(ptrs, ln, n_streams, P(bad), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec8), 0) == -2
 
 
+def test_host_pool_serves_concurrent_callers():
+    """An encoder and a decoder object of one process (bench.py's overlapped steps), or the lanes of one decoder, are inside the host
+    pool's parallel_for at the same time: six threads issue batch encodes and decodes of different sizes concurrently; every result
+    must equal the single-caller result."""
+    import threading
+    t = gc_tables()
+    st = tables_npz()["scale_table"]
+    L = lib()
+    P = lambda a: a.ctypes.data_as(C.c_void_p)
+    errors = []
+
+    def caller(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for it in range(12):
+                n_streams, n = int(rng.integers(2, 40)), int(rng.integers(50, 1500))
+                idx = rng.integers(0, 64, (n_streams, n)).astype(np.int32)
+                sym = np.rint(rng.standard_normal((n_streams, n)) * st[idx]).astype(np.int32)
+                stride = L.pc_rans_bound(n)
+                out = np.zeros((n_streams, stride), np.uint8)
+                lens = np.zeros(n_streams, np.uint64)
+                assert L.pc_rans_encode_batch(P(sym), P(idx), n_streams, n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(out), stride, P(lens), 0) == 0
+                enc = [out[i, : int(lens[i])].tobytes() for i in range(n_streams)]
+                assert enc[0] == entropy.rans_encode(sym[0], idx[0], t) and enc[-1] == entropy.rans_encode(sym[-1], idx[-1], t)
+                ptrs = (C.c_char_p * n_streams)(*enc)
+                ln = (C.c_size_t * n_streams)(*[len(e) for e in enc])
+                dec = np.zeros((n_streams, n), np.int32)
+                assert L.pc_rans_decode_batch_u8(ptrs, ln, n_streams, P(idx.astype(np.uint8)), n, P(t.cdf), 64, t.cdf.shape[1], P(t.length), P(t.offset), P(dec), 0) == 0
+                assert np.array_equal(dec, sym)
+        except BaseException as e:           # noqa: BLE001  (reported by the main thread)
+            errors.append(e)
+
+    threads = [threading.Thread(target=caller, args=(s,)) for s in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a caller is stuck in the pool"
+    assert not errors, errors
+
+
 def test_rans_edge_cases_and_errors():
     t = gc_tables()
     # empty input: the reference asserts / UB (rans_interface.cpp:170-172); we emit the 8-byte flush of the initial state
