@@ -1428,12 +1428,15 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         static const int tn_env = [] { const char* v = std::getenv("PC_CONV_TN"); return v ? std::atoi(v) : 0; }();
         e = hipErrorInvalidValue;
         if (kern_env == 1) {
-            // Tile choice (tools/conv_tune.py sweeps, profiles/r02_sweep3_*): 64x64 blocks (one 32x32 accumulator per wave) with three
-            // stages for the M = 8192 slice-chain GEMMs, where the number of workgroups is what fills the chip; 128x64 blocks (two
-            // accumulators per wave, 25 % less L2->LDS traffic, half the DMA / ds_read instructions per MFMA) with two stages once
-            // there are >= 6 of the smaller blocks per CU anyway (the high-resolution layers of g_a / g_s: +3..6 %).
+            // Kernel choice (PC_CONV_POLICY; tools/conv_tune.py, bench A/Bs: profiles/r02_l_*, r02_n_*, r02_o_*).  3 (default): K-chunk 16,
+            // three stages, 64x64 blocks -- 24 KB of LDS and 80 registers, up to six workgroups per CU -- for every layer with more than
+            // PC_CONV_SMALL_THR (256) blocks, i.e. more than one per CU; K-chunk 32 / three stages (two for K <= 256) for the small grids,
+            // where a workgroup is alone on its CU and the deeper prefetch per barrier counts.  1: K-chunk 16 everywhere.  2: K-chunk 16
+            // except 128x64 two-accumulator blocks on the large layers.  0: the first half of round 2 (K-chunk 32; 128x64 blocks with two
+            // stages once there are >= 1536 of the 64x64 blocks).  All of them produce identical bits.
             const long nb64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
-            static const int policy = [] { const char* v = std::getenv("PC_CONV_POLICY"); return v ? std::atoi(v) : 1; }();
+            static const int policy = [] { const char* v = std::getenv("PC_CONV_POLICY"); return v ? std::atoi(v) : 3; }();
+            static const long small_thr = [] { const char* v = std::getenv("PC_CONV_SMALL_THR"); return v ? std::atol(v) : 256L; }();
             static const long tm_thr = [] { const char* v = std::getenv("PC_CONV_TM_THR"); return v ? std::atol(v) : 1536L; }();
             int tm = tm_env ? tm_env : (nb64 >= tm_thr ? 2 : 1), tn = tn_env ? tn_env : 1;
             const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
@@ -1455,6 +1458,8 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             else if (bk == 16 && tm == 1 && tn == 1) e = launch_uni<16, 4, 1, 1>(p, stream);
             else if (policy == 1 && !s_env && !tm_env && !tn_env) e = launch_uni<16, 3, 1, 1>(p, stream);
             else if (policy == 2 && !s_env && !tm_env && !tn_env && tm == 1) e = launch_uni<16, 3, 1, 1>(p, stream);
+            else if (policy == 3 && !s_env && !tm_env && !tn_env && nb64 > small_thr) e = launch_uni<16, 3, 1, 1>(p, stream);
+            else if (policy == 3 && !s_env && !tm_env && !tn_env) e = chunks <= 8 ? launch_uni<32, 2, 1, 1>(p, stream) : launch_uni<32, 3, 1, 1>(p, stream);
 #define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
             PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
             PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2) PC_UNI_CASE(4, 1, 1)

@@ -40,6 +40,8 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
     ("ha_0", 32, 16, 16, 640, 320, 3, 1),
     ("gs_d6", 32, 64, 64, 192, 192, 5, -1),      # stride -1: ConvTranspose2d(5, s2) in four phases
     ("gs_d3", 32, 32, 32, 192, 192, 5, -1),
+    ("hs_8x8", 32, 8, 8, 224, 256, 3, 1),        # hyper-synthesis layers: few workgroups, long K
+    ("hs_4x4", 32, 4, 4, 192, 896, 3, 1),
 ]
 
 
