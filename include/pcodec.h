@@ -35,7 +35,8 @@ enum {
     PC_ERR_CDF = -5,        /* malformed CDF / pmf (reference: assert, ops.cpp:45; rans_interface.cpp:48-57) */
     PC_ERR_HIP = -6,        /* HIP runtime error (see pc_last_hip_error) */
     PC_ERR_NOMEM = -7,
-    PC_ERR_STATE = -8,      /* object not ready (e.g. tables not set: "Uninitialized CDFs. Run update() first") */
+    PC_ERR_STATE = -8,      /* object not ready (e.g. tables not set: "Uninitialized CDFs. Run update() first"), or busy: a codec object
+                               serves one compress / decompress / forward call at a time (use one object per concurrent caller) */
     PC_ERR_MISSING = -9     /* state_dict tensor missing or wrong shape */
 };
 

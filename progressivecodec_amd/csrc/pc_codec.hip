@@ -73,6 +73,7 @@ struct DevBuf { void* p = nullptr; size_t bytes = 0; };
 struct pc_codec {
     int device = 0;
     bool finalized = false;
+    std::atomic<bool> busy{false};               // a compress / decompress / forward call is inside: the object is not re-entrant
     pc_rowtab_cache* rowtabs = nullptr;          // per-geometry row tables of the conv kernel: owned here, freed in pc_codec_destroy
     std::map<std::string, HostTensor> sd;
     std::vector<void*> weight_allocs;
@@ -1489,6 +1490,15 @@ int ensure_pipeline(pc_codec* c, size_t M)
     return PC_OK;
 }
 
+// One call at a time per object: its workspaces, streams and staging buffers are the call's.  A second host thread entering the same
+// object gets PC_ERR_STATE instead of silently sharing them (two objects side by side are fine: bench.py).
+struct BusyGuard {
+    pc_codec* c;
+    bool ok;
+    explicit BusyGuard(pc_codec* cc) : c(cc), ok(false) { bool f = false; ok = c->busy.compare_exchange_strong(f, true, std::memory_order_acquire); }
+    ~BusyGuard() { if (ok) c->busy.store(false, std::memory_order_release); }
+};
+
 // compress() for a list of mask levels.  Everything that does not depend on the level -- g_a, h_a, the hyper-latent
 // strings, h_s and the ten base slices (CHProg_cnn.py:692-767) -- runs once; the enhancement chain (:775-845) runs once per
 // level with quality > 0.  The GPU always has the next pass queued while the host entropy-codes the previous one:
@@ -1502,6 +1512,8 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok()) return PC_ERR_STATE;
     if (c->eb.n != NCH) return PC_ERR_STATE;
+    BusyGuard busy(c);
+    if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     g_prof = c->profile ? c : nullptr;
     g_rowtabs = c->rowtabs;
@@ -1746,6 +1758,8 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
     if (!c || !x || !x_hat || !y_lik || !z_lik || B <= 0 || H <= 0 || W <= 0 || (H % 64) || (W % 64)) return PC_ERR_ARG;
     if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->eb_net) return PC_ERR_STATE;
+    BusyGuard busy(c);
+    if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     g_prof = c->profile ? c : nullptr;
@@ -1824,6 +1838,8 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     if (!c || !y_strings || !y_lens || !z_strings || !z_lens || !x_hat || !qualities || n_levels < 1 || B <= 0 || zh <= 0 || zw <= 0) return PC_ERR_ARG;
     if (mask_pol < PC_MASK_POINT_BASED_STD || mask_pol > PC_MASK_THREE_LEVELS_STD) return PC_ERR_ARG;
     if (!c->finalized || !c->gc.ok() || !c->eb.ok() || c->eb.n != NCH) return PC_ERR_STATE;
+    BusyGuard busy(c);
+    if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     g_prof = c->profile ? c : nullptr;
     g_rowtabs = c->rowtabs;

@@ -34,6 +34,18 @@ def _module_base():
     return torch.nn.Module
 
 
+def _one_call_at_a_time(fn):
+    """The C object is not re-entrant (a second caller gets PC_ERR_STATE) and the strings of a compress() are fetched after the call:
+    calls into one object from several host threads are serialised here.  Use two objects to run an encoder and a decoder side by side."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *a, **kw):
+        with self.__dict__["_call_lock"]:
+            return fn(self, *a, **kw)
+    return wrapper
+
+
 class ChannelProgresssiveWACNN(_module_base()):
     """A ``torch.nn.Module`` (isinstance checks, ``state_dict()``, ``parameters()``, ``eval()`` ... behave as the caller of the reference
     expects: SURVEY.md section 8b) whose tensors are host-side copies of what was loaded -- the working weights live packed in
@@ -55,6 +67,7 @@ class ChannelProgresssiveWACNN(_module_base()):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("progressivecodec_amd runs on a HIP device only (no CPU fallback)")
+        self.__dict__["_call_lock"] = __import__("threading").RLock()
         self._h = C.c_void_p()
         check(lib().pc_codec_create(C.byref(self._h), self.device.index or 0), "pc_codec_create")
         self._sd = None
@@ -229,6 +242,7 @@ class ChannelProgresssiveWACNN(_module_base()):
         check(lib().pc_codec_set_cust_map(self._h, C.c_void_p(cm.data_ptr())), "pc_codec_set_cust_map")
         return cm
 
+    @_one_call_at_a_time
     def compress(self, x, quality=0.0, mask_pol=None, cust_map=None):
         """CHProg_cnn.py:686-847.  Returns {"strings": [y_strings, z_strings], "shape", "masks"}."""
         import torch
@@ -257,6 +271,7 @@ class ChannelProgresssiveWACNN(_module_base()):
         return {"strings": [y_strings, z_strings], "shape": torch.Size([H // 64, W // 64]),
                 "masks": [masks[i] for i in range(10)] if masks is not None else []}
 
+    @_one_call_at_a_time
     def decompress(self, strings, shape, quality, mask_pol=None, cust_map=None):
         """CHProg_cnn.py:849-999.  Returns {"x_hat": Tensor[B,3,H,W] in [0,1]}."""
         import torch
@@ -282,6 +297,7 @@ class ChannelProgresssiveWACNN(_module_base()):
         return {"x_hat": x_hat}
 
     # ------------------------------------------------------------------ likelihood (rate estimation) path
+    @_one_call_at_a_time
     def forward_single_quality(self, x, quality, mask_pol="point-based-std", force_enhanced=False, training=False):
         """CHProg_cnn.py:1002-1198 in eval mode -- what test_epoch / valid_epoch call (training/step.py:215-267).
         Returns {"x_hat", "likelihoods": {"y", "z"}, "masks"}: y [B, 320 or 640, H/16, W/16], z [B, 192, H/64, W/64]; estimated
@@ -313,6 +329,7 @@ class ChannelProgresssiveWACNN(_module_base()):
                 "masks": [masks[i] for i in range(10)] if masks is not None else []}
 
     # ------------------------------------------------------------------ multi-level (shared base) coding
+    @_one_call_at_a_time
     def compress_levels(self, x, qualities, mask_pol=None):
         """compress() for a list of mask levels with the level-independent part (g_a, h_a, z, h_s, the ten base slices;
         CHProg_cnn.py:692-767) computed once -- SURVEY.md section 8(f) rank 1.  Returns one compress()-style dictionary per
@@ -351,6 +368,7 @@ class ChannelProgresssiveWACNN(_module_base()):
                         "masks": [masks[lv][i] for i in range(10)] if masks[lv] is not None else []})
         return out
 
+    @_one_call_at_a_time
     def decompress_levels(self, strings_per_level, shape, qualities, mask_pol=None):
         """decompress() for a list of levels of the same images: z, h_s and the ten base slices are decoded once
         (CHProg_cnn.py:855-904), each level decodes its enhancement chain and runs its synthesis transform.

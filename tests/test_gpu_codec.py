@@ -461,6 +461,109 @@ def test_4k_frame_two_levels_properties():
     assert 0.9 * bits <= coded <= 1.1 * bits
 
 
+def test_encoder_and_decoder_objects_side_by_side():
+    """bench.py's default schedule: a second codec object decodes batch i on its own stream and host thread while the first one
+    encodes batch i+1.  Every string and every reconstruction must equal what the same calls give one after the other, and the decoder
+    object must decode the encoder object's streams (same weights, same contract)."""
+    import queue
+    import threading
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from tests.util import synth_sd
+    enc = gpu_codec()
+    dec = ChannelProgresssiveWACNN(device="cuda:0")          # a second object of its own (gpu_codec() is cached: one object is not re-entrant)
+    dec.load_state_dict(synth_sd())
+    assert dec._h.value != enc._h.value
+    g = torch.Generator().manual_seed(77)
+    batches = [torch.rand(4, 3, 128, 128, generator=g).cuda() for _ in range(6)]
+    q = 0.5
+    want = []
+    for x in batches:                                           # the sequential answer, on the encoder object alone
+        o = enc.compress(x, q, "point-based-std")
+        want.append((o["strings"], enc.decompress(o["strings"], o["shape"], q, "point-based-std")["x_hat"].clone()))
+    qu, got, err = queue.Queue(maxsize=2), [], []
+    s_enc, s_dec = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def decoder():
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(s_dec):
+                while True:
+                    o = qu.get()
+                    if o is None:
+                        return
+                    got.append(dec.decompress(o["strings"], o["shape"], q, "point-based-std")["x_hat"].clone())
+        except BaseException as e:                              # noqa: BLE001
+            err.append(e)
+            while qu.get() is not None:
+                pass
+
+    th = threading.Thread(target=decoder)
+    th.start()
+    outs = []
+    with torch.cuda.stream(s_enc):
+        for rep in range(2):
+            for x in batches:
+                o = enc.compress(x, q, "point-based-std")
+                outs.append(o)
+                qu.put(o)
+    qu.put(None)
+    th.join(timeout=300)
+    assert not th.is_alive() and not err, err
+    s_enc.synchronize(); s_dec.synchronize()
+    assert len(got) == 12
+    for i, (o, xh) in enumerate(zip(outs, got)):
+        strings, x_want = want[i % 6]
+        assert o["strings"] == strings
+        assert torch.equal(xh, x_want)
+
+
+def test_one_object_from_two_threads():
+    """One object is not re-entrant (its workspaces, streams and result strings belong to the call in progress).  The Python mirror
+    serialises calls per object, so two threads get the right answers; at the C ABI a caller that finds the object busy gets
+    PC_ERR_STATE.  Nothing is silently corrupted either way."""
+    import ctypes as C
+    import threading
+    from progressivecodec_amd._lib import lib
+    net = gpu_codec()
+    g = torch.Generator().manual_seed(91)
+    xs = [torch.rand(2, 3, 128, 128, generator=g).cuda() for _ in range(2)]
+    want = [net.compress(x, 0.5, "point-based-std")["strings"] for x in xs]
+    good, bad = [0], []
+
+    def worker(i):
+        torch.cuda.set_device(0)
+        for _ in range(15):
+            s = net.compress(xs[i], 0.5, "point-based-std")["strings"]
+            if s == want[i]:
+                good[0] += 1
+            else:
+                bad.append("wrong strings")
+
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    assert not bad and good[0] == 30, (good, bad[:3])
+    # the C ABI underneath, without the mirror's lock
+    rcs = []
+
+    def raw(i):
+        torch.cuda.set_device(0)
+        for _ in range(15):
+            rcs.append(lib().pc_codec_compress(net._h, C.c_void_p(xs[i].data_ptr()), 2, 128, 128, 0.5, 0, None, None))
+
+    ths = [threading.Thread(target=raw, args=(i,)) for i in range(2)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=300)
+    torch.cuda.synchronize()
+    assert set(rcs) <= {0, -8} and rcs.count(0) > 0, rcs
+    print(f"same object, two threads at the C ABI: {rcs.count(0)} calls served, {rcs.count(-8)} refused with PC_ERR_STATE")
+    assert net.compress(xs[0], 0.5, "point-based-std")["strings"] == want[0]
+
+
 def test_config5_4k_frame_eight_levels_and_gather():
     """BASELINE Config 5 on one rank: one 3840x2160 frame (padded to 3840x2176), EIGHT progressive levels through the shared-base
     path, every level decoded, then the bitstream gather of bench.py over the process group (world size 1 here: RCCL on the GPU
