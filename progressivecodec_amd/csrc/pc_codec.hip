@@ -74,6 +74,7 @@ struct pc_codec {
     int device = 0;
     bool finalized = false;
     std::atomic<bool> busy{false};               // a compress / decompress / forward call is inside: the object is not re-entrant
+    hipEvent_t call_done = nullptr;              // recorded on the caller's stream when a call returns; the next call's stream waits for it
     pc_rowtab_cache* rowtabs = nullptr;          // per-geometry row tables of the conv kernel: owned here, freed in pc_codec_destroy
     std::map<std::string, HostTensor> sd;
     std::vector<void*> weight_allocs;
@@ -834,6 +835,7 @@ extern "C" void pc_codec_destroy(pc_codec* c)
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (auto& L : c->lanes) { (void)hipStreamDestroy(L.sA); (void)hipStreamDestroy(L.sB); (void)hipEventDestroy(L.eA); (void)hipEventDestroy(L.eB); (void)hipEventDestroy(L.eDone); }
     if (c->eFork) (void)hipEventDestroy(c->eFork);
+    if (c->call_done) (void)hipEventDestroy(c->call_done);
     for (hipEvent_t e : c->lvl_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
@@ -1498,6 +1500,20 @@ struct BusyGuard {
     explicit BusyGuard(pc_codec* cc) : c(cc), ok(false) { bool f = false; ok = c->busy.compare_exchange_strong(f, true, std::memory_order_acquire); }
     ~BusyGuard() { if (ok) c->busy.store(false, std::memory_order_release); }
 };
+// Calls into one object may arrive on different caller streams (decompress() returns with x_hat still in flight on its stream): the
+// object's workspaces must not be reused before the previous call's work is done.  Every call records `call_done` on its stream when
+// it returns, by whichever path, and the next call's stream waits for it first -- a no-op when it is the same stream.
+struct CallOrder {
+    pc_codec* c;
+    hipStream_t st;
+    int rc;
+    CallOrder(pc_codec* cc, hipStream_t s) : c(cc), st(s), rc(PC_OK)
+    {
+        if (!c->call_done) { if (hipEventCreateWithFlags(&c->call_done, hipEventDisableTiming) != hipSuccess) { c->call_done = nullptr; rc = PC_ERR_HIP; } }
+        else if (hipStreamWaitEvent(st, c->call_done, 0) != hipSuccess) rc = PC_ERR_HIP;
+    }
+    ~CallOrder() { if (c->call_done) (void)hipEventRecord(c->call_done, st); }
+};
 
 // compress() for a list of mask levels.  Everything that does not depend on the level -- g_a, h_a, the hyper-latent
 // strings, h_s and the ten base slices (CHProg_cnn.py:692-767) -- runs once; the enhancement chain (:775-845) runs once per
@@ -1515,6 +1531,8 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     BusyGuard busy(c);
     if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
+    CallOrder order(c, st);
+    if (order.rc != PC_OK) return order.rc;
     g_prof = c->profile ? c : nullptr;
     g_rowtabs = c->rowtabs;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
@@ -1762,6 +1780,8 @@ extern "C" int pc_codec_forward(pc_codec* c, const float* x, int B, int H, int W
     if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
+    CallOrder order(c, st);
+    if (order.rc != PC_OK) return order.rc;
     g_prof = c->profile ? c : nullptr;
     g_rowtabs = c->rowtabs;
     const int h = H / 16, w = W / 16, zh = H / 64, zw = W / 64, HW = h * w, ZHW = zh * zw;
@@ -1841,6 +1861,8 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     BusyGuard busy(c);
     if (!busy.ok) return PC_ERR_STATE;
     HIPCHK(hipSetDevice(c->device));
+    CallOrder order(c, st);
+    if (order.rc != PC_OK) return order.rc;
     g_prof = c->profile ? c : nullptr;
     g_rowtabs = c->rowtabs;
     const int h = 4 * zh, w = 4 * zw, HW = h * w, ZHW = zh * zw;

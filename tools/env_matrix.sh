@@ -1,0 +1,35 @@
+#!/bin/bash
+# The GPU test suite (minus the full-size Config 4 / 5 cases) under the run-time switches that select kernels, tiles, stages, lanes,
+# pipelining and host threads: every configuration must give the same bits.  usage (through gpurun): bash tools/env_matrix.sh > log
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
+fail=0
+ONLY=${1:-}
+run() {
+  if [ -n "$ONLY" ] && ! echo "$*" | grep -qE "$ONLY"; then return; fi
+  echo "== $*"
+  env "$@" timeout -k 10 400 python -m pytest tests -x -q -m gpu -k "not config4 and not config5 and not 4k_frame and not large_tiles" 2>&1 | tail -1
+  [ ${PIPESTATUS[0]} -eq 0 ] || fail=1
+}
+run PC_CONV_POLICY=0
+run PC_CONV_POLICY=1
+run PC_CONV_POLICY=2
+run PC_CONV_POLICY=3 PC_CONV_SMALL_THR=100000
+run PC_CONV_KERN=0
+run PC_CONV_BK=16 PC_CONV_S=2 PC_CONV_TM_THR=100000000
+run PC_CONV_BK=16 PC_CONV_S=4 PC_CONV_TM_THR=100000000
+run PC_CONV_BK=16 PC_CONV_S=6 PC_CONV_TM_THR=100000000
+run PC_CONV_S=2
+run PC_CONV_S=4 PC_CONV_TM_THR=100000000
+run PC_CONV_TM=2 PC_CONV_TN=2
+run PC_PREP_SCALAR=1
+run PC_DEC_FAST=0
+run PC_LANES=1
+run PC_LANES=3
+run PC_GROUPED=0 PC_DUAL_STREAM=0 PC_LANES=1
+run PC_PIPELINE=0
+run PC_PIPELINE_DEC=0
+run PC_HOST_THREADS=1
+run PC_HYPER_PARALLEL=0 PC_NO_STREAMED_ENCODE=1
+run GPU_MAX_HW_QUEUES=16
+echo "matrix failures: $fail"
+exit $fail
