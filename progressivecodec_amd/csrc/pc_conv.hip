@@ -36,6 +36,7 @@
 #include <new>
 #include <type_traits>
 #include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/pc_math.h"
@@ -723,7 +724,9 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     const int mpx = (MT + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
     const int m_local = slot / (NT * NZ), nz = slot - m_local * (NT * NZ);
-    const int m_tile = xcd * mpx + m_local;
+    // permuted rows: the cheap border tiles are the last tiles of the launch -- deal the tiles round-robin over the XCDs so that every
+    // XCD ends on its share of them (contiguous bands would leave them all to the last XCD and the launch would end no earlier)
+    const int m_tile = p.rowperm ? m_local * 8 + xcd : xcd * mpx + m_local;
     if (m_tile >= MT) return;
     const int zsel = nz / NT, n_tile = nz - zsel * NT;
     int phase = zsel;
@@ -738,13 +741,45 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     const int HoWo = p.Ho * p.Wo;
     int chunks_per_tap = 0;
     for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
-    const int nchunks = T * chunks_per_tap;
+    int Tv = T;                                            // taps this tile really visits (rowperm: fewer on border tiles)
+    uint32_t tmask = T >= 32 ? 0xffffffffu : ((1u << T) - 1u);
 
     // ---- this thread's DMA pieces: piece pa of the A image = (row pa / KQ, LDS slot pa % KQ) holds source k-quad slot ^ swz(row)
     constexpr int OOB = (int)0x80000000;
     int a_q[AIN], a_rel[AIN]; uint32_t a_mask[AIN];
     int64_t pix0;
-    if (p.rowtab) {
+    if (p.rowtab && p.rowperm) {
+        // permuted rows: the tile's rows may lie anywhere in the batch.  Offsets are taken from the tile's smallest pixel index
+        // (buffer offsets are unsigned), and the taps no row of the tile needs are dropped from the run table below.
+        __shared__ int s_minpix;
+        __shared__ uint32_t s_tmask;
+        if (threadIdx.x == 0) { s_minpix = 0x7fffffff; s_tmask = 0u; }
+        __syncthreads();
+        int pixv[AIN];
+        int mn = 0x7fffffff;
+        uint32_t orm = 0u;
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) {
+            const int pa = (wave * AIN + i) * 64 + lane;
+            const int row = pa / KQ, sl = pa % KQ;
+            a_q[i] = sl ^ pc_swz<KQ>(row);
+            const int m = m0 + row;
+            const bool ok = m < p.M;
+            pixv[i] = ok ? p.rowtab[m] : 0x7fffffff;
+            a_mask[i] = ok ? (uint32_t)p.rowtab[(size_t)(1 + phase) * p.M + m] : 0u;
+            mn = pixv[i] < mn ? pixv[i] : mn;
+            orm |= a_mask[i];
+        }
+        for (int off = 32; off; off >>= 1) { const int o = __shfl_xor(mn, off); mn = o < mn ? o : mn; orm |= (uint32_t)__shfl_xor((int)orm, off); }
+        if (lane == 0) { atomicMin(&s_minpix, mn); atomicOr(&s_tmask, orm); }
+        __syncthreads();
+        pix0 = s_minpix;
+        tmask &= s_tmask;
+        if (tmask == 0u) tmask = 1u;                       // (a tile without a live row: keep one tap so that the loops stay well-formed)
+        Tv = __popc(tmask);
+#pragma unroll
+        for (int i = 0; i < AIN; ++i) a_rel[i] = pixv[i] == 0x7fffffff ? 0 : pixv[i] - (int)pix0;
+    } else if (p.rowtab) {
         pix0 = p.rowtab[m0];
 #pragma unroll
         for (int i = 0; i < AIN; ++i) {
@@ -806,10 +841,13 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
     int runs_per_tap = 0;
     for (int sg = 0; sg < p.nseg; ++sg) runs_per_tap += (p.seg[sg].nch >= BK ? 1 : 0) + (p.seg[sg].nch % BK ? 1 : 0);
-    const int nruns = T * runs_per_tap;
+    const int nchunks = Tv * chunks_per_tap;
+    const int nruns = Tv * runs_per_tap;
     for (int r = threadIdx.x; r < nruns; r += NTH) {
-        const int t = r / runs_per_tap;
-        int rr = r - t * runs_per_tap, sg = 0, cbase = 0, ch0 = 0, nch = 0;
+        const int tv = r / runs_per_tap;                   // the tv-th tap this tile visits = the tv-th set bit of tmask
+        int t = 0;
+        { uint32_t mk = tmask; for (int q = 0; q < tv; ++q) mk &= mk - 1u; t = __ffs((int)mk) - 1; }
+        int rr = r - tv * runs_per_tap, sg = 0, cbase = 0, ch0 = 0, nch = 0;
         for (;; ++sg) {                                    // locate run rr of this tap: (segment, full part or remainder)
             const int full = p.seg[sg].nch / BK * BK, rem = p.seg[sg].nch - full;
             const int here = (full ? 1 : 0) + (rem ? 1 : 0);
@@ -1111,15 +1149,16 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
                         if (a == 1 && !u1) break;
-                        const float* src = (a == 0 ? p.aux0 : p.aux1) + (int64_t)mb * (a == 0 ? p.ld0 : p.ld1) + nb;
                         const int ld = a == 0 ? p.ld0 : p.ld1;
+                        const float* src = (a == 0 ? p.aux0 : p.aux1) + (p.rowperm ? (int64_t)0 : (int64_t)mb * ld) + nb;
                         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
                             const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
+                            const int prow = (p.rowperm && ok) ? p.rowtab[mb + row] : row;      // permuted rows: the aux row is the row's pixel
                             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
-                                                                     ok ? (row * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
+                                                                     ok ? (prow * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
                         }
                     }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1132,7 +1171,8 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                         float v = acc[i][j][r];
                         if (bias) v = v + bv;
                         const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
-                        outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
+                        const int64_t opix = p.rowperm ? (int64_t)p.rowtab[m] : (int64_t)m;
+                        outp[opix * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
                     }
                 }
             } else {
@@ -1178,7 +1218,7 @@ __global__ void conv_rowtab_kernel(const pc_conv_params p, int* __restrict__ tab
 }
 
 struct RowTabKey {
-    int dev, B, H, W, stride, nphase, Ho, Wo, M, ntap[4];
+    int dev, B, H, W, stride, nphase, Ho, Wo, M, perm, ntap[4];
     int dy[4][PC_MAX_TAP], dx[4][PC_MAX_TAP];
     bool operator==(const RowTabKey& o) const { return std::memcmp(this, &o, sizeof(*this)) == 0; }
 };
@@ -1251,7 +1291,7 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
     RowTabKey k;
     std::memset(&k, 0, sizeof(k));
     (void)hipGetDevice(&k.dev);
-    k.B = p.B; k.H = p.H; k.W = p.W; k.stride = p.stride; k.nphase = p.nphase; k.Ho = p.Ho; k.Wo = p.Wo; k.M = p.M;
+    k.B = p.B; k.H = p.H; k.W = p.W; k.stride = p.stride; k.nphase = p.nphase; k.Ho = p.Ho; k.Wo = p.Wo; k.M = p.M; k.perm = p.rowperm;
     for (int ph = 0; ph < p.nphase; ++ph) {
         k.ntap[ph] = p.ntap[ph];
         for (int t = 0; t < p.ntap[ph]; ++t) { k.dy[ph][t] = p.dy[ph][t]; k.dx[ph][t] = p.dx[ph][t]; }
@@ -1276,8 +1316,32 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
     e.key = k; e.bytes = bytes; e.done = false; e.tick = ++rc->tick; e.tab = nullptr;
     if (hipMalloc(reinterpret_cast<void**>(&e.tab), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) { (void)hipFree(e.tab); return nullptr; }
-    hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, e.tab);
-    if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
+    if (p.rowperm) {
+        // rows grouped by tap-validity pattern (interior first, then one group per border pattern): built on the host once per geometry
+        // (stride 1, one phase, small images only: M <= a few 10^4), copied synchronously -- it is ready for every stream at once
+        std::vector<int> host((size_t)2 * p.M);
+        std::vector<std::pair<uint32_t, int>> order((size_t)p.M);
+        const uint32_t full = p.ntap[0] >= 32 ? 0xffffffffu : ((1u << p.ntap[0]) - 1u);
+        for (int m = 0; m < p.M; ++m) {
+            const int b = m / (p.H * p.W), r = m - b * p.H * p.W, y = r / p.W, x = r - y * p.W;
+            uint32_t mask = 0;
+            for (int t = 0; t < p.ntap[0]; ++t) {
+                const int iy = y + p.dy[0][t], ix = x + p.dx[0][t];
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
+            }
+            order[(size_t)m] = {mask == full ? 0u : mask, m};          // sort key: interior rows first
+        }
+        std::stable_sort(order.begin(), order.end(), [](const std::pair<uint32_t, int>& a, const std::pair<uint32_t, int>& b2) { return a.first < b2.first; });
+        for (int m = 0; m < p.M; ++m) {
+            host[(size_t)m] = order[(size_t)m].second;
+            host[(size_t)p.M + m] = (int)(order[(size_t)m].first == 0u ? full : order[(size_t)m].first);
+        }
+        if (hipMemcpy(e.tab, host.data(), bytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
+        e.done = true;
+    } else {
+        hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, e.tab);
+        if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
+    }
     rc->bytes += bytes;
     rc->map.emplace(h, e);
     return e.tab;
@@ -1378,7 +1442,25 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         int tmax = 0;
         for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
         static const bool no_tab = [] { const char* v = std::getenv("PC_CONV_NO_ROWTAB"); return v && std::atoi(v) != 0; }();
+        // Padding taps (PC_CONV_ROWPERM, default on): on small images a 3x3 window multiplies zero padding for 8 % (16x16), 16 % (8x8),
+        // 30 % (4x4) of its MACs.  A tile of consecutive pixels always mixes border and interior rows; with the rows grouped by
+        // tap-validity pattern a border tile skips its padding taps as whole runs.  A chain never holds -0 (it starts at +0, exact
+        // cancellation rounds to +0), so dropping fmaf(0, w, acc) terms keeps the bits.  Stride 1, "same" output grid, one phase,
+        // unified kernel, dense NHWC output, 32-bit piece offsets.
+        static const bool perm_on = [] { const char* v = std::getenv("PC_CONV_ROWPERM"); return !v || std::atoi(v) != 0; }();
+        static const bool uni_on = [] { const char* v = std::getenv("PC_CONV_KERN"); return !v || std::atoi(v) == 1; }();
+        static const long perm_min_blocks = [] { const char* v = std::getenv("PC_CONV_ROWPERM_MIN"); return v ? std::atol(v) : 256L; }();
+        int maxld = 0;
+        for (int sg = 0; sg < p.nseg; ++sg) maxld = std::max(maxld, p.seg[sg].ld);
+        maxld = std::max(maxld, std::max(p.ld0, p.ld1));
+        const bool dense = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho && p.outW == p.Wo &&
+                           !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx && p.out_sb == (int64_t)p.outH * p.out_sy;
+        p.rowperm = (perm_on && uni_on && !no_tab && p.wlayout == 1 && !p.square && !p.smallc && tmax > 1 && tmax <= 25 && p.nphase == 1 && p.stride == 1 &&
+                     p.Ho == p.H && p.Wo == p.W && p.H <= 32 && p.W <= 32 && dense && !(p.dbg & 64) &&
+                     (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : 1) > perm_min_blocks &&   // one block per CU: the launch lasts as long as its interior tiles
+                     (int64_t)p.B * p.H * p.W * (int64_t)std::max(maxld, 1) * 4 < ((int64_t)1 << 31)) ? 1 : 0;
         p.rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
+        if (!p.rowtab) p.rowperm = 0;
     }
     p.ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
                                                 p.Ho == p.H && p.Wo == p.W;

@@ -73,6 +73,8 @@ struct pc_conv_params {
     void* rowtab_cache;                      // pc_rowtab_cache* of the calling codec (null: the process-wide cache of the stand-alone entry points)
     int ident_rows;                          // set by pc_conv_launch: 1x1 stride-1 layer, GEMM row m reads input pixel m (no row table)
     int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
+    int rowperm;                             // set by pc_conv_launch: the row table is a PERMUTATION of the pixels (rows grouped by tap-validity
+                                             // pattern, so that a tile's padding taps can be skipped as whole runs); output pixel of row m = rowtab[m]
     int dbg;                                 // tuning only (PC_CONV_DBG bits): 1 skip MFMAs, 2 skip DMA issue, 4 DMAs read the zero page, 64 stamps, 256 print occupancy
 };
 

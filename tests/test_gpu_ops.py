@@ -80,6 +80,13 @@ CONV_CASES = [
     (8, 64, 64, 96, 96, 3, 1, 1, 0),     # >= 1024 blocks: K-chunk 32 LDS-DMA kernel, N tail 96 = 64 + 32
     (4, 16, 16, 640, 320, 1, 1, 0, 0),   # 1x1 with K = 640 (LDS-DMA kernel, 10 chunks)
     (2, 16, 16, 160, 160, 3, 1, 1, 0),   # Cin = 160: K-chunk 64 with a 32-channel segment tail
+    # rows permuted by tap-validity pattern, padding taps skipped per tile (stride 1, images up to 32x32)
+    (5, 16, 16, 128, 64, 3, 1, 1, 0),    # 1280 rows: pattern groups end inside tiles
+    (3, 4, 4, 192, 96, 3, 1, 0, 0),      # every pixel on the border
+    (7, 1, 1, 64, 64, 3, 1, 0, 0),       # only the centre tap is ever valid
+    (2, 32, 32, 64, 64, 3, 1, 1, 0),
+    (1, 2, 3, 48, 32, 3, 1, 0, 0),
+    (2, 16, 16, 32, 32, 5, 1, 0, 0),     # 25 taps
 ]
 
 

@@ -21,6 +21,8 @@ run PC_CONV_BK=16 PC_CONV_S=6 PC_CONV_TM_THR=100000000
 run PC_CONV_S=2
 run PC_CONV_S=4 PC_CONV_TM_THR=100000000
 run PC_CONV_TM=2 PC_CONV_TN=2
+run PC_CONV_ROWPERM=0
+run PC_CONV_ROWPERM_MIN=0
 run PC_PREP_SCALAR=1
 run PC_DEC_FAST=0
 run PC_LANES=1
