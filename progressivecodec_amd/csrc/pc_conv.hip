@@ -1144,37 +1144,45 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             const int n = nb + l31;
             const float bv = (bias && n < p.Cout) ? bias[n] : 0.0f;
             if (p.dense_out) {
-                if (u0) {
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads of this region are complete
+                // PERM (compile-time in each copy): permuted rows -- the output / aux pixel of tile row `row` is rowtab[mb + row].  The
+                // plain copy is the code as it was: a run-time select in the store loop cost the aux epilogues 5-15 %.
+                auto dense_tile = [&](auto perm_tag) {
+                    constexpr bool PERM = decltype(perm_tag)::value;
+                    if (u0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads of this region are complete
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) {
-                        if (a == 1 && !u1) break;
-                        const int ld = a == 0 ? p.ld0 : p.ld1;
-                        const float* src = (a == 0 ? p.aux0 : p.aux1) + (p.rowperm ? (int64_t)0 : (int64_t)mb * ld) + nb;
-                        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
+                        for (int a = 0; a < 2; ++a) {
+                            if (a == 1 && !u1) break;
+                            const int ld = a == 0 ? p.ld0 : p.ld1;
+                            const float* src = (a == 0 ? p.aux0 : p.aux1) + (PERM ? (int64_t)0 : (int64_t)mb * ld) + nb;
+                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
-                            const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
-                            const int prow = (p.rowperm && ok) ? p.rowtab[mb + row] : row;      // permuted rows: the aux row is the row's pixel
-                            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
-                                                                     ok ? (prow * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
+                            for (int k = 0; k < 4; ++k) {
+                                const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
+                                const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
+                                int prow = row;
+                                if (PERM) prow = ok ? p.rowtab[mb + row] : 0;
+                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
+                                                                         ok ? (prow * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
+                            }
+                        }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    if (n < p.Cout) {
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+                            const int m = mb + row;
+                            if (m >= p.M) continue;
+                            float v = acc[i][j][r];
+                            if (bias) v = v + bv;
+                            const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
+                            int64_t opix = m;
+                            if (PERM) opix = p.rowtab[m];
+                            outp[opix * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
                         }
                     }
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                }
-                if (n < p.Cout) {
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const int m = mb + row;
-                        if (m >= p.M) continue;
-                        float v = acc[i][j][r];
-                        if (bias) v = v + bv;
-                        const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
-                        const int64_t opix = p.rowperm ? (int64_t)p.rowtab[m] : (int64_t)m;
-                        outp[opix * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
-                    }
-                }
+                };
+                if (p.rowperm) dense_tile(std::true_type{}); else dense_tile(std::false_type{});
             } else {
                 for (int r = 0; r < 16; ++r) {
                     const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
