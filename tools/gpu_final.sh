@@ -1,14 +1,11 @@
 #!/bin/bash
-# final GPU pass of a round: configuration matrix, profile round, default bench, other configs -- everything written under gpurun_out/
+# final GPU pass of a round, in two gpurun calls (one call may run 1200 s at most):
+#   gpurun -- 'bash tools/env_matrix.sh > gpurun_out/TAG_env_config_matrix_gpu_tests.log'      (23 configurations of the GPU suite, ~17 min)
+#   gpurun -- 'bash tools/gpu_final.sh TAG'                                                   (this file: suite, smoke, profile round, bench lines)
 set -o pipefail
 TAG=${1:-r02_z}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; mkdir -p $O
 cd $R
-bash tools/env_matrix.sh 2>&1 | tee $O/${TAG}_env_config_matrix_gpu_tests.log | grep -E "^==|passed|failed|matrix"
 echo "== full gpu tests"; timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/${TAG}_gpu_tests.log 2>&1; rc=$?; tail -2 $O/${TAG}_gpu_tests.log; [ $rc -eq 0 ] || exit 1
 echo "== smoke"; timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; rc=$?; tail -1 $O/${TAG}_smoke.log; [ $rc -eq 0 ] || exit 1
-echo "== profile round"; bash tools/profile_round.sh $TAG > $O/profile_round_$TAG.log 2>&1 || { tail -5 $O/profile_round_$TAG.log; exit 1; }
-mkdir -p $R/profiles && cp $O/profiles_$TAG/* $R/profiles/      # on the box only: lets the bench below find this build's traffic profile
-echo "== default bench"; timeout -k 10 600 python bench.py > $O/${TAG}_bench_default.log 2>&1; rc=$?; tail -1 $O/${TAG}_bench_default.log | cut -c1-260; [ $rc -eq 0 ] || exit 1
-echo "== configs"; timeout -k 10 300 python tools/configs_bench.py 2 > $O/${TAG}_configs_3_4_5_bench.jsonl 2>/dev/null; cut -c1-160 $O/${TAG}_configs_3_4_5_bench.jsonl
-echo "== long bench"; timeout -k 10 300 python bench.py --steps 60 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_60steps.log 2>&1; tail -1 $O/${TAG}_bench_60steps.log | cut -c1-200
+bash tools/gpu_final2.sh $TAG
