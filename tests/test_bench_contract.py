@@ -1,0 +1,45 @@
+"""The bench line contract, checked on the committed record of the round's final build (profiles/r*_bench_default.log: the JSON line
+`python bench.py` printed on an MI355X).  No GPU needed: this guards the shape of the line -- keys, units, the roofline and CPU-baseline
+objects -- and that the record carries this build's source hash when the kernel sources have not changed since it was taken."""
+import glob
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_line():
+    logs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default.log")))
+    assert logs, "no committed bench record"
+    lines = [l for l in open(logs[-1]).read().splitlines() if l.startswith("{")]
+    assert lines, logs[-1]
+    return json.loads(lines[-1]), os.path.basename(logs[-1])
+
+
+def test_bench_line_contract():
+    j, name = _last_line()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, (name, k)
+    assert j["unit"] == "MP/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "workload" in j["config"] and "model" not in j["config"]
+    assert abs(j["value"] - j["n_gpus"] * 32 * 256 * 256 / 1e6 / (j["ms_per_step"] * 1e-3)) < 0.02 * j["value"]
+    r = j["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = j["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_committed_profiles_belong_to_this_build():
+    """bench.py takes `traffic` and the stage figures only from profiles measured on the build it runs (source hash); the newest
+    committed set must be that build's, or the driver's bench line at round end carries nulls."""
+    from bench import newest_profile, source_hash
+    src = source_hash()
+    for pattern in ("r*_hbm_traffic.json", "r*_stage_kernels_rocprof.json"):
+        j, why = newest_profile(pattern, src)
+        assert j is not None, why
