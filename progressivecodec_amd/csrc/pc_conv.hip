@@ -1148,6 +1148,14 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                 // plain copy is the code as it was: a run-time select in the store loop cost the aux epilogues 5-15 %.
                 auto dense_tile = [&](auto perm_tag) {
                     constexpr bool PERM = decltype(perm_tag)::value;
+                    // permuted rows: the 32 pixel indices of this tile's rows go through LDS (the run table's space: the K loop is over).
+                    // Read from global memory inside the store loop they put a `vmcnt(0)` -- which on gfx9 also counts the stores
+                    // in flight -- in front of every store: sixteen store round trips per tile, one after the other.
+                    int* prow_lds = reinterpret_cast<int*>(runs) + wave * 32;
+                    if (PERM) {
+                        if (lane < 32) prow_lds[lane] = mb + lane < p.M ? p.rowtab[mb + lane] : 0;
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    }
                     if (u0) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads of this region are complete
 #pragma unroll
@@ -1161,7 +1169,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                                 const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
                                 const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
                                 int prow = row;
-                                if (PERM) prow = ok ? p.rowtab[mb + row] : 0;
+                                if (PERM) prow = prow_lds[row];
                                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
                                                                          ok ? (prow * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
                             }
@@ -1177,7 +1185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
                             if (bias) v = v + bv;
                             const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
                             int64_t opix = m;
-                            if (PERM) opix = p.rowtab[m];
+                            if (PERM) opix = prow_lds[row];
                             outp[opix * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
                         }
                     }
