@@ -58,7 +58,7 @@ def launch_ranks(n, argv):
     import socket
 
     import torch
-    have = torch.cuda.device_count()                        # (counting devices does not initialise the GPU)
+    have = torch.cuda.device_count()                        # the ranks are fresh child processes: nothing they do depends on this process's GPU state
     if have < n:
         print(f"[bench] --gpus {n} asked for, this node exposes {have} GPU(s): refusing to run a smaller job under that label "
               f"(launch under torchrun on a node with {n} GPUs)", file=sys.stderr, flush=True)
@@ -228,17 +228,23 @@ def main():
                 box["err"] = e
                 while qu.get() is not None:
                     pass
-        th = threading.Thread(target=decoder)
+        th = threading.Thread(target=decoder, daemon=True)     # daemon: a failure on either side ends the process, never a hang at exit
         th.start()
         o = None
-        with torch.cuda.stream(s_enc):
-            for _ in range(n):
-                o = net.compress(x, q, MASK_POL)
-                qu.put(o)
-        qu.put(None)
-        th.join()
+        try:
+            with torch.cuda.stream(s_enc):
+                for _ in range(n):
+                    if "err" in box:                             # the decoder died: stop feeding it
+                        break
+                    o = net.compress(x, q, MASK_POL)
+                    qu.put(o)
+        finally:
+            qu.put(None)                                         # always: the decoder thread must see the end of the queue
+            th.join(timeout=600)
         if "err" in box:
             raise box["err"]
+        if th.is_alive():
+            raise RuntimeError("decoder thread did not finish")
         s_enc.synchronize(); s_dec.synchronize()
         return o, box["dec"]
 
@@ -344,6 +350,8 @@ def main():
     line["mask_entropy_stage"] = ({"source": f"profiles/{swhy}", **{k: v for k, v in sj.items() if k not in ("source_hash",)}} if sj is not None
                                   else {"source": None, "why": swhy})
 
+    if rank == 0:                                                  # rank 0's batch is the golden's batch (seed 1)
+        line["reference_parity"] = reference_parity(out, dec["x_hat"].cpu(), x.cpu(), q)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (bench contract)
         line["cpu_baseline"] = cpu_baseline_leg(net, sd, x, q, args, log)
     if rank == 0:
@@ -398,7 +406,7 @@ def cpu_baseline_leg(net, sd, x, q, args, log):
     psnr = lambda a, b: -10.0 * torch.log10(torch.mean((a - b) ** 2)).item()
     flip_free = [b for b, f in enumerate(first) if f is None]
     d_ff = max((abs(psnr(xc[b], d["x_hat"][b]) - psnr(xc[b], gd[b])) for b in flip_free), default=None)
-    return {"value": round(reps * n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
+    port = {"value": round(reps * n_img * S * S / 1e6 / dt, 4), "unit": "MP/s", "cores": cores, "kind": "port",
             "sample": f"{n_img} of the {x.shape[0]} images of rank 0 ({S}x{S}, q={q}) as one batch, encode+decode x{reps}, "
                       f"torch {torch.__version__} CPU ops + C rANS, {dt:.1f} s",
             "bpp": round(8.0 * nb(o["strings"]) / (n_img * S * S), 6), "psnr_db": round(psnr(xc, d["x_hat"]), 6),
@@ -412,6 +420,49 @@ def cpu_baseline_leg(net, sd, x, q, args, log):
                            "note": "differing elements inside each flipped image's FIRST diverging slice (the float-rounding flips themselves; "
                                    "later slices differ because their context differs)"},
             "max_abs_psnr_diff_db_flip_free_images": d_ff, "north_star_tolerance_db": 1e-4}
+    # the port is the TIMED baseline; its symbol-level differences above are against this box's oneDNN.  The parity figure of the
+    # headline configuration is the one against the reference itself:
+    port["vs_port_note"] = ("the *_to_gpu / flip / mismatch fields above compare the GPU with the CPU port run on THIS box (its oneDNN build, "
+                            f"{cores} threads); the line's `reference_parity` compares the GPU with the committed output of the reference itself")
+    return port
+
+
+def reference_parity(g, gd, xc, q):
+    """The GPU's strings and reconstruction of this batch against the REAL reference's (tests/golden/config2.json: made in the build
+    container by tests/golden/make_golden_config2.py, which imports /root/reference; 8 threads): the parity figure of the headline
+    configuration is pinned to the reference itself, not to the CPU port run on this box (VERDICT r02 "What's weak" 1)."""
+    import math
+    from progressivecodec_amd.harness import compare_with_golden_strings
+    gp = os.path.join(ROOT, "tests", "golden", "config2.json")
+    if not os.path.exists(gp):
+        return {"source": None, "why": "tests/golden/config2.json missing"}
+    gj = json.load(open(gp))
+    r = gj["runs"][0]
+    B, S = xc.shape[0], xc.shape[-1]
+    if (B, S, q) != (gj["B"], gj["H"], gj["quality"]):
+        return {"source": None, "why": f"golden is for {gj['B']} x {gj['H']}^2 at q={gj['quality']}, this run is {B} x {S}^2 at q={q}"}
+    import torch
+    x_ref = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(gj["seed"]))
+    if not torch.equal(x_ref, xc):
+        return {"source": None, "why": "this rank's batch is not the golden's batch"}
+    c = compare_with_golden_strings(g["strings"], r["y_sha"], r["z_sha"])
+    ps = lambda a, b: -10.0 * math.log10(torch.mean((a - b) ** 2).item())
+    d = [abs(ps(xc[b], gd[b].clamp(0, 1)) - r["psnr_per_image"][b]) for b in range(B)]
+    ff = c["flip_free_images"]
+    nb = sum(len(s) for sl in g["strings"][0] for s in sl) + sum(len(s) for s in g["strings"][1])
+    other = [{"threads": o["threads"], "y_strings_identical_to_8_threads": sum(a == b_ for sa, sb in zip(r["y_sha"], o["y_sha"]) for a, b_ in zip(sa, sb)),
+              "z_strings_identical_to_8_threads": sum(a == b_ for a, b_ in zip(r["z_sha"], o["z_sha"]))} for o in gj["runs"][1:]]
+    return {"source": "tests/golden/config2.json (the reference itself, imported in the build container, torch %s CPU, %d threads)" % (r["torch"], r["threads"]),
+            "reference_bpp": round(r["bpp"], 6), "reference_psnr_db": round(r["psnr"], 6),
+            "gpu_bpp": round(8.0 * nb / (B * S * S), 6), "gpu_psnr_db": round(ps(xc, gd.clamp(0, 1)), 6),
+            "z_strings_identical": f"{c['z_strings_identical']}/{B}", "y_strings_identical": f"{c['y_strings_identical']}/{c['y_strings']}",
+            "flip_free_images": f"{len(ff)}/{B}", "first_diverging_slice_histogram": c["first_diverging_slice_histogram"],
+            "max_abs_psnr_diff_db_flip_free_images": max((d[b] for b in ff), default=None),
+            "flip_free_images_within_1e-4_db": f"{sum(d[b] <= 1e-4 for b in ff)}/{len(ff)}",
+            "max_abs_psnr_diff_db_flipped_images": max((d[b] for b in range(B) if b not in ff), default=None),
+            "images_within_1e-4_db": f"{sum(v <= 1e-4 for v in d)}/{B}",
+            "reference_at_other_thread_counts_same_machine": other,
+            "north_star_tolerance_db": 1e-4}
 
 
 if __name__ == "__main__":

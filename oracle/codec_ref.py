@@ -589,7 +589,8 @@ class RemCodec(RefCodec):
         if quality <= c[0]:
             return scale
         q_bar, _ = self.find_check_quality(quality)
-        att = torch.round(self._mask(scale, quality, mask_pol) - self._mask(scale, q_bar, mask_pol))
+        # the reference's call sites (:620,832,1060) do not forward mask_pol: the attention mask is always "point-based-std" (:385)
+        att = torch.round(self._mask(scale, quality, "point-based-std") - self._mask(scale, q_bar, "point-based-std"))
         if len(c) == 1:
             k = 0
         elif len(c) == 2:

@@ -1181,7 +1181,9 @@ int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_
     PCCHK(c->buf("rem_thr" + tag, (size_t)2 * k.B, &thr2));
     // attention mask = round(star - bar), both thresholds on the UNREFINED scale (:386-396)
     float qs = 0, qb = 0;
-    const int mode_star = mask_mode_for(k.mask_pol, q, &qs), mode_bar = mask_mode_for(k.mask_pol, q_bar, &qb);
+    // The reference never forwards the caller's mask_pol here (CHProgREM.py:620,832,1060 pass `training` only; the parameter's default
+    // at :385 is "point-based-std"): the attention mask is quantile-based whatever policy the block mask uses.
+    const int mode_star = mask_mode_for(PC_MASK_POINT_BASED_STD, q, &qs), mode_bar = mask_mode_for(PC_MASK_POINT_BASED_STD, q_bar, &qb);
     uint32_t* qw;
     PCCHK(quantile_work(k, nb, tag, &qw));
     if (mode_star == 1) PCCHK(pc_quantile_thr_launch(sc_i, SLICE, nb, k.HW, SLICE, qs, thr2, qw, st));

@@ -1246,7 +1246,10 @@ struct RowTabKey {
 // sees thousands of distinct image sizes keeps a bounded amount of HBM.  A table is built asynchronously on the stream
 // that first needs it; other streams order themselves behind its `ready` event -- no host synchronisation on the launch path.
 struct pc_rowtab_cache {
-    struct Entry { RowTabKey key; int* tab; size_t bytes; hipEvent_t ready; bool done; uint64_t tick; };
+    // `pins` counts the launches that were handed this table and have not been enqueued yet (conv_rowtab pins, pc_conv_launch unpins
+    // right behind hipLaunchKernelGGL): a pinned table is never evicted, so another host thread's make_room cannot free it between
+    // the lookup and the launch; once the launch is enqueued the device drain in front of the hipFree covers it.
+    struct Entry { RowTabKey key; int* tab; size_t bytes; hipEvent_t ready; bool done; uint64_t tick; int pins; };
     std::mutex mu;
     std::unordered_multimap<uint64_t, Entry> map;
     size_t bytes = 0, cap;
@@ -1266,19 +1269,32 @@ struct pc_rowtab_cache {
         map.clear();
         bytes = 0;
     }
-    // evict least-recently-used tables until `need` more bytes fit; the device is drained first (a launch in flight may still read them)
-    void make_room(size_t need)
+    // Called with `mu` held: unlink least-recently-used, unpinned tables until `need` more bytes fit.  The victims are only taken out of
+    // the map here; the caller drains the device and frees them AFTER dropping the lock (a launch already enqueued may still read
+    // them, and a device drain under the lock would stall every other lane's lookups).
+    void unlink_victims(size_t need, std::vector<Entry>& victims)
     {
-        if (bytes + need <= cap || map.empty()) return;
-        (void)hipDeviceSynchronize();
-        while (bytes + need > cap && !map.empty()) {
-            auto victim = map.begin();
-            for (auto it = map.begin(); it != map.end(); ++it) if (it->second.tick < victim->second.tick) victim = it;
-            (void)hipFree(victim->second.tab);
-            (void)hipEventDestroy(victim->second.ready);
+        while (bytes + need > cap) {
+            auto victim = map.end();
+            for (auto it = map.begin(); it != map.end(); ++it)
+                if (it->second.pins == 0 && (victim == map.end() || it->second.tick < victim->second.tick)) victim = it;
+            if (victim == map.end()) break;                // everything left is pinned: go over the cap rather than free a table in use
             bytes -= victim->second.bytes;
+            victims.push_back(victim->second);
             map.erase(victim);
         }
+    }
+    static void free_victims(std::vector<Entry>& victims)
+    {
+        if (victims.empty()) return;
+        (void)hipDeviceSynchronize();
+        for (auto& v : victims) { (void)hipFree(v.tab); (void)hipEventDestroy(v.ready); }
+        victims.clear();
+    }
+    void unpin(const int* tab)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto& kv : map) if (kv.second.tab == tab) { if (kv.second.pins > 0) --kv.second.pins; return; }
     }
 };
 
@@ -1299,7 +1315,8 @@ pc_rowtab_cache* default_rowtab_cache()
     return &cache;
 }
 
-// the cached table for this layer geometry, built on first use on `stream`; nullptr = fall back to in-kernel row arithmetic
+// the cached table for this layer geometry, built on first use on `stream`; nullptr = fall back to in-kernel row arithmetic.
+// The table comes back PINNED: the caller unpins it (conv_rowtab_unpin) once its launch is enqueued.
 const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
 {
     if ((int64_t)p.B * p.H * p.W >= (int64_t)1 << 31) return nullptr;          // pixel indices are int32 in the table
@@ -1313,23 +1330,35 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
         for (int t = 0; t < p.ntap[ph]; ++t) { k.dy[ph][t] = p.dy[ph][t]; k.dx[ph][t] = p.dx[ph][t]; }
     }
     const uint64_t h = pc_rowtab_cache::hash(k);
-    std::lock_guard<std::mutex> lk(rc->mu);
-    auto range = rc->map.equal_range(h);
-    for (auto it = range.first; it != range.second; ++it) {
-        pc_rowtab_cache::Entry& e = it->second;
-        if (!(e.key == k)) continue;
-        e.tick = ++rc->tick;
-        if (!e.done) {                                     // built on another stream a moment ago: order this stream behind it
-            if (hipEventQuery(e.ready) == hipSuccess) e.done = true;
-            else if (hipStreamWaitEvent(stream, e.ready, 0) != hipSuccess) return nullptr;
-        }
-        return e.tab;
-    }
     const size_t bytes = (size_t)(1 + p.nphase) * p.M * sizeof(int);
-    if (bytes > rc->cap) return nullptr;
-    rc->make_room(bytes);
+    // look the geometry up; on a hit order this stream behind the table's build and pin it
+    auto lookup = [&](const int** out) -> bool {             // with rc->mu held
+        auto range = rc->map.equal_range(h);
+        for (auto it = range.first; it != range.second; ++it) {
+            pc_rowtab_cache::Entry& e = it->second;
+            if (!(e.key == k)) continue;
+            e.tick = ++rc->tick;
+            if (!e.done) {                                 // built on another stream a moment ago: order this stream behind it
+                if (hipEventQuery(e.ready) == hipSuccess) e.done = true;
+                else if (hipStreamWaitEvent(stream, e.ready, 0) != hipSuccess) { *out = nullptr; return true; }
+            }
+            ++e.pins;
+            *out = e.tab;
+            return true;
+        }
+        return false;
+    };
+    std::vector<pc_rowtab_cache::Entry> victims;
+    {
+        std::lock_guard<std::mutex> lk(rc->mu);
+        const int* hit = nullptr;
+        if (lookup(&hit)) return hit;
+        if (bytes > rc->cap) return nullptr;
+        rc->unlink_victims(bytes, victims);
+    }
+    pc_rowtab_cache::free_victims(victims);                // device drain + hipFree outside the lock
     pc_rowtab_cache::Entry e;
-    e.key = k; e.bytes = bytes; e.done = false; e.tick = ++rc->tick; e.tab = nullptr;
+    e.key = k; e.bytes = bytes; e.done = false; e.tick = 0; e.tab = nullptr; e.pins = 1;
     if (hipMalloc(reinterpret_cast<void**>(&e.tab), bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     if (hipEventCreateWithFlags(&e.ready, hipEventDisableTiming) != hipSuccess) { (void)hipFree(e.tab); return nullptr; }
     if (p.rowperm) {
@@ -1358,9 +1387,26 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
         hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, e.tab);
         if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
     }
+    std::lock_guard<std::mutex> lk(rc->mu);
+    const int* other = nullptr;
+    if (lookup(&other) && other) {
+        // another lane built the same geometry while this one was building outside the lock: use (and pin) that table.  Ours may already
+        // be read by nothing (its build kernel is the only work queued on it): drop it after that kernel has run.
+        std::vector<pc_rowtab_cache::Entry> mine{e};
+        pc_rowtab_cache::free_victims(mine);
+        return other;
+    }
+    e.tick = ++rc->tick;
     rc->bytes += bytes;
     rc->map.emplace(h, e);
     return e.tab;
+}
+
+void conv_rowtab_unpin(const pc_conv_params& p)
+{
+    if (!p.rowtab) return;
+    pc_rowtab_cache* rc = p.rowtab_cache ? reinterpret_cast<pc_rowtab_cache*>(p.rowtab_cache) : default_rowtab_cache();
+    rc->unpin(p.rowtab);
 }
 
 template <int BK, int S, int WM, int WN, bool SQ = false>
@@ -1451,6 +1497,10 @@ int pc_conv_weight_layout(int kind, int Cin, int Cout, int k)
 int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
 {
     pc_conv_params p = p_in;                               // derived fields (row table, fast-path flags, debug bits) are set on a private copy
+    p.rowtab = nullptr;
+    // the row table comes back pinned in its cache; it is unpinned when this function returns, i.e. once the launch is enqueued (from then
+    // on the device drain in front of an eviction's hipFree protects it) or on any early error return
+    struct Unpin { const pc_conv_params& q; ~Unpin() { conv_rowtab_unpin(q); } } unpin_guard{p};
     if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
     static const int dbg_env = [] { const char* v = std::getenv("PC_CONV_DBG"); return v ? std::atoi(v) : 0; }();
     if (dbg_env) p.dbg = dbg_env;

@@ -5,13 +5,59 @@ Per image: centre zero-pad to a multiple of 64 (step.py:318-319, compressai.ops.
 for every level `p` of `pr_list`: compress -> decompress (only the decode is timed, step.py:332-340),
 un-pad and clamp (step.py:342-343), PSNR = -10 log10(mean((x - x_hat)^2)) (step.py:13-18,349),
 bpp = 8 * (sum of the byte-string lengths) / (H*W) over the UNPADDED size (step.py:357-365).
-File reading, MS-SSIM, wandb logging and the text dump of step.py are outside the hot path.
+File reading, wandb logging and the text dump of step.py are outside the hot path.
+
+Return signature: the reference returns (bpp, psnr, mssim, dec_time) per level (step.py:404); this harness returns
+(bpp, psnr, dec_time, rows) -- the MS-SSIM column (step.py:350-353, `pytorch_msssim.ms_ssim`) is NOT produced: that package is
+absent from this image and from the GPU box, the reference holds no MS-SSIM fixture, so any restatement would be parity-unpinned.
+Callers that need it can compute it from the x_hat of decompress() with their own MS-SSIM.
 """
 import math
 import time
 
 #: the level list the authors evaluate (train.py:293)
 PR_LIST = [0, 0.05, 0.1, 0.25, 0.5, 0.6, 0.75, 1, 1.25, 2, 3, 5, 10]
+
+
+def config3_images(n=24, first_seed=100):
+    """BASELINE.json Config 3 stand-in for the Kodak set (no Kodak files exist offline): `n` tensors [1,3,512,768]
+    drawn with torch.rand from seeds first_seed .. first_seed+n-1; every fourth one (index 3, 7, 11, ...: six of 24, as many as Kodak has
+    portrait images) is transposed to 768x512.  Shared by tests, tools/configs_bench.py and tests/golden/make_golden_config3.py."""
+    import torch
+    out = []
+    for i in range(n):
+        x = torch.rand(1, 3, 512, 768, generator=torch.Generator().manual_seed(first_seed + i))
+        out.append(x.transpose(2, 3).contiguous() if i % 4 == 3 else x)
+    return out
+
+
+def compare_with_golden_strings(strings, y_sha, z_sha):
+    """What separates byte strings made here from a committed fixture of the reference's (sha256 per string: tests/golden/config2.json,
+    config3.json).  strings = [y_strings[slice][image], z_strings[image]] as compress() returns them; y_sha[slice][image], z_sha[image].
+    Returns a dict: identical-string counts, per image the first diverging y slice (None: every y string identical; -1: the
+    hyper-latent string already differs), the flip-free image list and the histogram of first diverging slices.  An image is
+    "flip-free" when all of its strings equal the reference's; float rounding (the reference's oneDNN summation order vs the numeric
+    contract's fmaf chain) that flips one round() or compare makes an image differ from that slice on."""
+    import hashlib
+    sha = lambda b: hashlib.sha256(b).hexdigest()
+    ys, zs = strings
+    B = len(zs)
+    z_same = [sha(zs[b]) == z_sha[b] for b in range(B)]
+    same = [[sha(ys[s][b]) == y_sha[s][b] for b in range(B)] for s in range(len(ys))]
+    first = []
+    for b in range(B):
+        if not z_same[b]:
+            first.append(-1)
+            continue
+        f = next((s for s in range(len(ys)) if not same[s][b]), None)
+        first.append(f)
+    hist = {}
+    for f in first:
+        if f is not None:
+            hist[str(f)] = hist.get(str(f), 0) + 1
+    return {"images": B, "z_strings_identical": sum(z_same), "y_strings_identical": sum(sum(r) for r in same), "y_strings": len(ys) * B,
+            "first_diverging_slice": first, "flip_free_images": [b for b, f in enumerate(first) if f is None],
+            "first_diverging_slice_histogram": dict(sorted(hist.items(), key=lambda kv: int(kv[0])))}
 
 
 def compute_padding(in_h, in_w, min_div=64):

@@ -134,6 +134,14 @@ class ChannelProgresssiveWACNN(_module_base()):
     def load_state_dict(self, state_dict, strict=True, _extra=None):
         """models/cnn.py:195-202 / base.py:62-70: accepts the reference's 1019-key state_dict.  (_extra: tensors of a wrapping model --
         the REM's post_latent.* -- handed to the native codec before it is finalised.)"""
+        if self._finalized:
+            # a second load (the reference's usual REM flow: load the base net, wrap it, then rem.load_state_dict(base, post) --
+            # CHProgREM.py:361-369): the native object is immutable once finalised, so it is replaced by a fresh one
+            with self._call_lock:
+                lib().pc_codec_destroy(self._h)
+                self._h = C.c_void_p()
+                check(lib().pc_codec_create(C.byref(self._h), self.device.index or 0), "pc_codec_create")
+                self._finalized = False
         for k, a in (_extra or {}).items():
             a = np.ascontiguousarray(a, np.float32)
             shp = (C.c_int64 * a.ndim)(*a.shape)

@@ -40,7 +40,12 @@ class PostRateProcessedNetwork:
             spec = rem_param_spec(self.check_multiple, self.dimension)
             missing = [k for k in spec if k not in state_dict_post]
             if missing:
+                # (the native REM needs every post_latent tensor whatever `strict` says: a CNN with absent weights cannot run; the
+                # reference's strict=False would leave them at their random initialisation)
                 raise RuntimeError(f"post_latent state dict lacks {missing[:4]}...")
+            unexpected = [k for k in state_dict_post if k not in spec]
+            if strict and unexpected:
+                raise RuntimeError(f"Error(s) in loading state_dict for post_latent: unexpected {unexpected[:4]}...")
             extra = {}
             for k, (shape, dtype, _) in spec.items():
                 v = state_dict_post[k]
@@ -49,7 +54,7 @@ class PostRateProcessedNetwork:
                     raise RuntimeError(f"size mismatch for post_latent.{k}: {tuple(a.shape)} vs {tuple(shape)}")
                 extra["post_latent." + k] = a
             self._post = {k[len("post_latent."):]: v for k, v in extra.items()}
-        self.base_net.load_state_dict(state_dict_base, strict=True, _extra=extra)
+        self.base_net.load_state_dict(state_dict_base, strict=strict, _extra=extra)   # honours `strict` (reference default False, :361)
         return self
 
     def update(self, *a, **kw):

@@ -49,17 +49,22 @@ def spy(current_index, quality, quality_bar, y_b_hat, mu_scale_base, mu_scale_en
 
 rem.apply_latent_enhancement = spy
 out = []
-for name, B, H, W, seed, kind, quals in (("rem_b2_64", 2, 64, 64, 11, "rand", [0.005, 0.1, 0.5, 2, 10]), ("rem_b1_64x128", 1, 64, 128, 17, "smooth", [1.0])):
+# (the last two rows, ADVICE r02: the block mask follows the caller's mask_pol, the attention mask of apply_latent_enhancement never does --
+#  the call sites at CHProgREM.py:620,832,1060 do not forward it -- so with "two-levels" the refinement is still quantile-gated)
+for name, B, H, W, seed, kind, quals, pol in (("rem_b2_64", 2, 64, 64, 11, "rand", [0.005, 0.1, 0.5, 2, 10], "point-based-std"),
+                                              ("rem_b1_64x128", 1, 64, 128, 17, "smooth", [1.0], "point-based-std"),
+                                              ("rem_b2_64_two_levels", 2, 64, 64, 11, "rand", [1.0], "two-levels"),
+                                              ("rem_b1_64x128_three_levels", 1, 64, 128, 17, "smooth", [1.0], "three-levels-std")):
     x = inputs(B, H, W, seed, kind)
     for q in quals:
         cap.clear()
         with torch.no_grad():
-            o = rem.compress(x, quality=q, mask_pol="point-based-std")
-            d = rem.decompress(o["strings"], o["shape"], q, mask_pol="point-based-std")
+            o = rem.compress(x, quality=q, mask_pol=pol)
+            d = rem.decompress(o["strings"], o["shape"], q, mask_pol=pol)
         ys, zs = o["strings"]
         x_hat = d["x_hat"].clamp(0, 1)
         nbytes = sum(len(s) for sl in ys for s in sl) + sum(len(s) for s in zs)
-        out.append(dict(case=name, B=B, H=H, W=W, seed=seed, kind=kind, quality=q, shape=list(o["shape"]),
+        out.append(dict(case=name, B=B, H=H, W=W, seed=seed, kind=kind, quality=q, mask_pol=pol, shape=list(o["shape"]),
                         y_sha=[[sha(s) for s in sl] for sl in ys], z_sha=[sha(s) for s in zs],
                         mask_sums=[[int(m[b].sum().item()) for b in range(B)] for m in o["masks"]],
                         bpp=8.0 * nbytes / (B * H * W), psnr=-10.0 * math.log10(torch.mean((x - x_hat) ** 2).item()),

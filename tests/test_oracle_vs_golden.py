@@ -265,7 +265,7 @@ def rem_oracle(backend):
     return RemCodec(synth_sd(), rem_post_sd(), backend)
 
 
-@pytest.mark.parametrize("idx", [0, 1, 3, 4, 5])
+@pytest.mark.parametrize("idx", [0, 1, 3, 4, 5, 6, 7])
 def test_rem_torch_backend_equals_reference(idx):
     """PostRateProcessedNetwork.compress()/decompress() (CHProgREM.py:673,896): every byte string, mask popcount, the refined scale
     of slice 3 and the x_hat hash of the reference (tests/golden/make_golden_rem.py) reproduced by the oracle's ATen back-end --
@@ -275,12 +275,13 @@ def test_rem_torch_backend_equals_reference(idx):
     x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
     orc = rem_oracle("torch")
     taps = {}
-    out = orc.compress(x, c["quality"], taps=taps)
+    pol = c.get("mask_pol", "point-based-std")       # cases 6, 7: the block mask follows the policy, the attention mask does not
+    out = orc.compress(x, c["quality"], pol, taps=taps)
     ys, zs = out["strings"]
     assert [sha(s) for s in zs] == c["z_sha"]
     assert [[sha(s) for s in sl] for sl in ys] == c["y_sha"]
     assert [[int(m[b].sum()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
     assert np.array_equal(taps["e3"]["scale"].flatten()[::37].numpy(), np.asarray(c["scale3_sub"], np.float32))
-    dec = orc.decompress(out["strings"], out["shape"], c["quality"])["x_hat"].clamp(0, 1)
+    dec = orc.decompress(out["strings"], out["shape"], c["quality"], pol)["x_hat"].clamp(0, 1)
     assert sha(dec.numpy().tobytes()) == c["x_hat_sha"]
     assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) < 1e-12

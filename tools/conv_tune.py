@@ -42,6 +42,18 @@ SHAPES = [  # name, B, H, W, Cin, Cout, k, stride
     ("gs_d3", 32, 32, 32, 192, 192, 5, -1),
     ("hs_8x8", 32, 8, 8, 224, 256, 3, 1),        # hyper-synthesis layers: few workgroups, long K
     ("hs_4x4", 32, 4, 4, 192, 896, 3, 1),
+    # Round 3 probe -- what a 3-way split of the K chain could give at most (no reduction cost): the same FLOPs as the stack layers above
+    # run as three times the rows with a third of the channels each (K = 9 * Cin/3, rounded to the 16-channel granule)
+    ("ks3g_L1", 192, 16, 16, 176, 224, 3, 1),
+    ("ks3g_L2", 192, 16, 16, 80, 176, 3, 1),
+    ("ks3g_L3", 192, 16, 16, 64, 128, 3, 1),
+    ("ks3g_L4", 192, 16, 16, 48, 64, 3, 1),
+    ("ks3g_L5", 192, 16, 16, 16, 32, 3, 1),
+    ("ks3_L1", 96, 16, 16, 176, 224, 3, 1),
+    ("ks3_L2", 96, 16, 16, 80, 176, 3, 1),
+    ("ks3_L3", 96, 16, 16, 64, 128, 3, 1),
+    ("ks3_L4", 96, 16, 16, 48, 64, 3, 1),
+    ("ks3_L5", 96, 16, 16, 16, 32, 3, 1),
 ]
 
 
