@@ -138,10 +138,14 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--quality", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lean", action="store_true", help="profiling runs: only the timed steps, the enc/dec split and the roofline leg -- no CPU baseline, "
+                    "no rANS leg (it codes a 4K frame), no second (sequential) timed run; the kernel trace then holds the headline schedule only")
     ap.add_argument("--overlap", type=int, default=1, help="1 (default): the decode of step i runs beside the encode of step i+1 -- an encoder and a "
                     "decoder codec object on their own streams and host threads; 0: compress() then decompress(), one after the other")
     ap.add_argument("--cpu-images", type=int, default=32, help="images of rank 0's batch the CPU port codes (x2 repetitions)")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = True
 
     under_launcher = "RANK" in os.environ and "WORLD_SIZE" in os.environ
     if not under_launcher and args.gpus > 1:
@@ -267,6 +271,30 @@ def main():
         elapsed = float(t.item())
     barrier()
 
+    # per-rank spread (a straggler must be visible the day the scaling curve is run): min / max over ranks of this rank's own time
+    rank_ms = 1e3 * (t1 - t0) / args.steps
+    rank_ms_min = rank_ms_max = rank_ms
+    if world > 1:
+        t = torch.tensor([rank_ms, -rank_ms], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rank_ms_max, rank_ms_min = float(t[0].item()), -float(t[1].item())
+
+    # the same K steps strictly one after the other on ONE codec object (what a drop-in compress_with_ac caller sees): `sequential_value`
+    seq_value = None
+    if args.overlap and not args.lean:
+        barrier()
+        ts0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize(dev)
+        seq_elapsed = time.perf_counter() - ts0
+        if world > 1:
+            t = torch.tensor([seq_elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seq_elapsed = float(t.item())
+        seq_value = world * B * S * S * args.steps / 1e6 / seq_elapsed
+        log(f"sequential {args.steps} steps: {seq_elapsed:.3f} s")
+
     # encode / decode split (informational; one extra step)
     torch.cuda.synchronize(dev)
     ta = time.perf_counter()
@@ -337,6 +365,10 @@ def main():
                                      "overlaps the encode of step i+1 (encoder and decoder codec objects, two streams, two host threads)")
                    if args.overlap else "every step = compress() then decompress(), strictly one after the other",
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
+        "sequential_value": round(seq_value, 3) if seq_value else (None if args.overlap else round(value, 3)),
+        "sequential_note": "the same steps strictly one after the other on one codec object (--overlap 0 schedule): what a drop-in "
+                           "compress_with_ac caller sees; `value` is the overlapped schedule named in config.step_schedule",
+        "rank_ms_per_step": {"min": round(rank_ms_min, 3), "max": round(rank_ms_max, 3)},
         "serial_step_ms": round(1e3 * (tc - ta), 2),
         "enc_ms": round(1e3 * (tb - ta), 2), "dec_ms": round(1e3 * (tc - tb), 2),
         "bpp": round(bpp, 4), "psnr_db": round(psnr, 4), "coded_bytes_job": total_bytes,
@@ -350,6 +382,14 @@ def main():
     line["mask_entropy_stage"] = ({"source": f"profiles/{swhy}", **{k: v for k, v in sj.items() if k not in ("source_hash",)}} if sj is not None
                                   else {"source": None, "why": swhy})
 
+    if rank == 0 and not args.lean:
+        try:
+            line["rans"] = rans_leg(net, x, q, log)
+        except Exception as e:                                     # a measurement aid must not take the headline down
+            line["rans"] = {"error": repr(e)}
+    oj, owhy = newest_profile("r*_overlap_schedule_mfma.json", src)
+    line["roofline"]["overlapped_schedule"] = ({"source": f"profiles/{owhy}", **{k: v for k, v in oj.items() if k != "source_hash"}} if oj is not None
+                                               else {"source": None, "why": owhy})
     if rank == 0:                                                  # rank 0's batch is the golden's batch (seed 1)
         line["reference_parity"] = reference_parity(out, dec["x_hat"].cpu(), x.cpu(), q)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # rank 0 at N = 1 only (bench contract)
@@ -359,6 +399,72 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def rans_leg(net, x, q, log):
+    """"rANS: report Msym/s per stream and streams in flight".  Host entropy coder on the REAL symbol planes of
+    this batch (read back from the codec's taps): serial per-stream rates, the pool's rate on one slice step, the host ms the codec itself
+    spent coding in one compress / decompress call and how much of it nothing hides -- for Config 2, and for one Config-5 frame
+    (3840x2160, one level), where a stream is 1.04 M symbols and the per-slice decode sits on the serial chain."""
+    import numpy as np
+    import torch
+    import torch.nn.functional as F
+    from progressivecodec_amd import entropy
+    from progressivecodec_amd.harness import compute_padding
+    L = lib_()
+    nt, first, allowed = C.c_int(), C.c_int(), C.c_int()
+    L.pc_host_pool_plan(C.byref(nt), C.byref(first), C.byref(allowed))
+
+    def one(xb, label):
+        B, H, W = xb.shape[0], xb.shape[2], xb.shape[3]
+        per = 32 * (H // 16) * (W // 16)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        o = net.compress(xb, q, MASK_POL)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st = (C.c_double * 6)()
+        L.pc_codec_host_stats(net._h, st, 6)
+        enc = list(st)
+        sym = net.read_tap("sym", np.int32)[: 20 * B * per].reshape(20 * B, per)
+        idx = net.read_tap("idx", np.int32)[: 20 * B * per].reshape(20 * B, per)
+        t2 = time.perf_counter()
+        net.decompress(o["strings"], o["shape"], q, MASK_POL)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        L.pc_codec_host_stats(net._h, st, 6)
+        dec = list(st)
+        rates = entropy.measure_rans_rates(sym, idx, net._gc, nt.value, streams_per_call=B, sample=48 if per <= 65536 else 6, reps=2)
+        nbytes = sum(len(s_) for sl in o["strings"][0] for s_ in sl)
+        log(f"rans leg {label}: enc {1e3 * (t1 - t0):.1f} ms (host coding {enc[1]:.2f}, exposed {enc[2]:.2f}), dec {1e3 * (t3 - t2):.1f} ms (host decode {dec[3]:.2f})")
+        return {"workload": label, "streams_per_slice_step": B, "symbols_per_stream": per, "slice_steps_per_call": 20,
+                "symbols_per_call": int(enc[4]), "y_bytes": nbytes,
+                "compress_ms": round(1e3 * (t1 - t0), 2), "host_encode_ms_in_compress": round(enc[1], 3), "host_encode_ms_exposed": round(enc[2], 3),
+                "decompress_ms": round(1e3 * (t3 - t2), 2), "host_decode_ms_in_decompress_summed_over_chains": round(dec[3], 3),
+                "host_decode_note": "each slice's decode sits between two GPU steps of its chain (base and enhancement chains run one slice apart "
+                                    "on two host threads, so each hides behind the other's kernels; in the overlapped bench also behind the encoder object)",
+                **rates}
+
+    out = {"pool": {"threads": nt.value, "first_cpu": first.value, "cpus_allowed": allowed.value, "decode_streams_per_thread": 2},
+           "config2": one(x, f"Config 2: {x.shape[0]} x {x.shape[2]}x{x.shape[3]}, q={q}")}
+    try:
+        g = torch.Generator().manual_seed(5)
+        lo = torch.rand(1, 3, 270, 480, generator=g)
+        f = (F.interpolate(lo, size=(2160, 3840), mode="bilinear", align_corners=False) + 0.03 * torch.randn(1, 3, 2160, 3840, generator=g)).clamp(0, 1)
+        pad, _ = compute_padding(2160, 3840)
+        xf = F.pad(f, pad).to(x.device)
+        one(xf, "warm-up")
+        out["config5_frame"] = one(xf, f"Config 5: one 3840x2160 frame (padded to 3840x2176), one level q={q}")
+        del xf
+        torch.cuda.empty_cache()
+    except Exception as e:
+        out["config5_frame"] = {"error": repr(e)}
+    return out
+
+
+def lib_():
+    from progressivecodec_amd._lib import lib
+    return lib()
 
 
 def cpu_baseline_leg(net, sd, x, q, args, log):

@@ -258,6 +258,13 @@ PC_API int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_
 /* algorithmic HBM bytes (every operand of a launch once: input, weights, bias, output, aux tensors) summed over the launches recorded
  * since pc_codec_profile_begin; read it after pc_codec_profile_end */
 PC_API int pc_codec_profile_bytes(const pc_codec* c, double* total_algorithmic_bytes);
+/* Host entropy-coding figures of the object's last compress / decompress call ("rANS: report Msym/s per stream
+ * and streams in flight"; no reference counterpart -- the reference times decompress() as a whole, training/step.py:332-340).
+ * out[0] wall ms of the last compress call, out[1] host ms spent in rANS encoding during it (mostly hidden behind the GPU chain),
+ * out[2] of those, the ms of the last pass that nothing hides ("exposed"), out[3] host ms of rANS decoding in the last decompress call
+ * summed over the decoder's lanes (each slice's decode sits between two GPU steps of its chain), out[4] / out[5] symbols encoded /
+ * decoded by those calls.  n >= 6. */
+PC_API int pc_codec_host_stats(const pc_codec* c, double* out, int n);
 
 /* Debug/test taps: copy an internal device tensor of the last call to host ("y", "z", "latent_means", ...). */
 PC_API int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap_floats, size_t* n_floats);

@@ -127,6 +127,9 @@ struct pc_codec {
     hipEvent_t eFork = nullptr;
     std::mutex buf_mu;
     double t_host_decode_ms = 0.0;
+    // host entropy-coding figures of the last compress / decompress call (pc_codec_host_stats)
+    double t_compress_ms = 0.0, t_host_encode_ms = 0.0, t_host_encode_exposed_ms = 0.0, t_decompress_ms = 0.0;
+    double n_sym_encoded = 0.0, n_sym_decoded = 0.0;
     // last-call geometry for taps
     int last_B = 0, last_h16 = 0, last_w16 = 0;
 
@@ -1704,6 +1707,8 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         if (r != PC_OK) rc = r;
     }
     HIPCHK(hipStreamSynchronize(st));                                                    // masks_out complete for the caller
+    c->t_compress_ms = now() - t0; c->t_host_encode_ms = t_host; c->t_host_encode_exposed_ms = t_enc_last;
+    c->n_sym_encoded = (double)B * ZHW * NCH + (double)n_half * (1 + n_coded);
     if (timing) std::fprintf(stderr, "[pcodec] compress: %d level(s), %d coded; total %.2f ms; host rANS of the last pass (exposed) %.2f ms\n",
                              n_levels, n_coded, now() - t0, t_enc_last);
     return rc;
@@ -1955,6 +1960,11 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         }
         PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990
     }
+    {
+        int n_enh = 0;
+        for (int l = 0; l < n_levels; ++l) n_enh += qualities[l] != 0 ? 1 : 0;
+        c->n_sym_decoded = (double)per_z * B + (double)per * B * NS0 * (1 + n_enh);
+    }
     if (std::getenv("PC_TIMING")) std::fprintf(stderr, "[pcodec] decompress: %d level(s), host rANS decode (summed over lanes) %.2f ms\n", n_levels, c->t_host_decode_ms);
     return PC_OK;
 }
@@ -2020,6 +2030,14 @@ extern "C" int pc_codec_profile_bytes(const pc_codec* c, double* total_algorithm
 {
     if (!c || !total_algorithmic_bytes) return PC_ERR_ARG;
     *total_algorithmic_bytes = c->prof_bytes;                 // of the launches recorded since the last pc_codec_profile_begin
+    return PC_OK;
+}
+
+extern "C" int pc_codec_host_stats(const pc_codec* c, double* out, int n)
+{
+    if (!c || !out || n < 6) return PC_ERR_ARG;
+    out[0] = c->t_compress_ms; out[1] = c->t_host_encode_ms; out[2] = c->t_host_encode_exposed_ms;
+    out[3] = c->t_host_decode_ms; out[4] = c->n_sym_encoded; out[5] = c->n_sym_decoded;
     return PC_OK;
 }
 

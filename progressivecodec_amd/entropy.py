@@ -206,3 +206,75 @@ def entropy_bottleneck_tables(sd, prefix="entropy_bottleneck") -> CdfTables:
     tail = torch.sigmoid(lower[:, 0, :1]) + torch.sigmoid(-upper[:, 0, -1:])
     cdf = _pmf_to_cdf(pmf.numpy(), tail.numpy(), pmf_length.numpy(), max_length)
     return CdfTables(cdf, (pmf_length + 2).numpy(), (-minima).numpy())
+
+
+def measure_rans_rates(sym, idx, t: CdfTables, n_threads, streams_per_call=32, sample=48, reps=3):
+    """Host rANS coder rates on real symbol planes ("rANS: report Msym/s per stream and streams in flight").
+    sym, idx: [n_streams][n] int32 as the encoder chain produced them (one stream per image and slice).  Measures
+      * one stream at a time on one host thread: pc_rans_encode_with_indexes / pc_rans_decode_with_indexes (the serial per-stream rate:
+        a stream is one chain of dependent state updates, rans_interface.cpp:99-275) and the decoder's fast form on two streams in lock
+        step (pc_rans_decode_batch_u8, one thread);
+      * the process's pool coding `streams_per_call` streams per call on `n_threads` threads, as one slice step of the codec does.
+    Returns a dict of Msym/s figures.  Used by bench.py and tools/host_pool_scale.py; pure host code."""
+    import time
+    L = lib()
+    sym = np.ascontiguousarray(sym, np.int32)
+    idx = np.ascontiguousarray(idx, np.int32)
+    ns, n = sym.shape
+    pick = np.unique(np.linspace(0, ns - 1, min(sample, ns)).astype(int))
+    cap = L.pc_rans_bound(n)
+    buf = np.empty(cap, np.uint8)
+    ln = C.c_size_t(0)
+    tab = (_ptr(t.cdf), t.cdf.shape[0], t.cdf.shape[1], _ptr(t.length), _ptr(t.offset))
+    enc = {}
+    t_enc = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for s in pick:
+            check(L.pc_rans_encode_with_indexes(_ptr(sym[s]), _ptr(idx[s]), n, *tab, _ptr(buf), cap, C.byref(ln)), "rans_encode")
+            enc[int(s)] = buf[: ln.value].tobytes()
+        t_enc = min(t_enc, time.perf_counter() - t0)
+    out = np.empty(n, np.int32)
+    t_dec = 1e30
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for s in pick:
+            e = np.frombuffer(enc[int(s)], np.uint8)
+            check(L.pc_rans_decode_with_indexes(_ptr(e), e.size, _ptr(idx[s]), n, *tab, _ptr(out)), "rans_decode")
+        t_dec = min(t_dec, time.perf_counter() - t0)
+    assert np.array_equal(out, sym[pick[-1]])
+    # pool: one slice step = streams_per_call streams per call
+    k = min(streams_per_call, ns)
+    s0 = (ns // 2) // k * k if ns >= 2 * k else 0                 # a slice from the middle of the chain (an enhancement slice if there is one)
+    sb, ib = sym[s0:s0 + k], idx[s0:s0 + k]
+    ob = np.empty((k, cap), np.uint8)
+    lens = (C.c_size_t * k)()
+    t_pe = 1e30
+    for _ in range(reps + 2):
+        t0 = time.perf_counter()
+        check(L.pc_rans_encode_batch(_ptr(sb), _ptr(ib), k, n, *tab, _ptr(ob), cap, lens, n_threads), "rans_encode_batch")
+        t_pe = min(t_pe, time.perf_counter() - t0)
+    ptrs = (C.c_void_p * k)(*[ob[i].ctypes.data for i in range(k)])
+    i8 = np.ascontiguousarray(ib.astype(np.uint8))
+    ob2 = np.empty((k, n), np.int32)
+    t_pd, t_1d = 1e30, 1e30
+    for _ in range(reps + 2):
+        t0 = time.perf_counter()
+        check(L.pc_rans_decode_batch_u8(ptrs, lens, k, _ptr(i8), n, *tab, _ptr(ob2), n_threads), "rans_decode_batch_u8")
+        t_pd = min(t_pd, time.perf_counter() - t0)
+    assert np.array_equal(ob2, sb)
+    k2 = min(2, k)
+    for _ in range(reps + 2):
+        t0 = time.perf_counter()
+        check(L.pc_rans_decode_batch_u8(ptrs, lens, k2, _ptr(i8), n, *tab, _ptr(ob2), 1), "rans_decode_batch_u8")
+        t_1d = min(t_1d, time.perf_counter() - t0)
+    coded_bytes = sum(len(v) for v in enc.values())
+    return {"symbols_per_stream": int(n), "streams_sampled": int(len(pick)),
+            "bits_per_symbol_sampled": round(8.0 * coded_bytes / (len(pick) * n), 3),
+            "encode_msym_s_per_stream": round(len(pick) * n / t_enc / 1e6, 1),
+            "decode_msym_s_per_stream": round(len(pick) * n / t_dec / 1e6, 1),
+            "decode_fast_msym_s_per_stream_two_in_lock_step": round(n / t_1d / 1e6, 1),
+            "decode_fast_msym_s_per_thread": round(k2 * n / t_1d / 1e6, 1),
+            "pool_threads": int(n_threads), "streams_in_flight": int(k),
+            "pool_encode_msym_s": round(k * n / t_pe / 1e6, 1), "pool_decode_msym_s": round(k * n / t_pd / 1e6, 1),
+            "pool_encode_ms_per_slice_step": round(1e3 * t_pe, 3), "pool_decode_ms_per_slice_step": round(1e3 * t_pd, 3)}

@@ -991,7 +991,7 @@ def test_config3_kodak_sized_set_all_13_levels():
             x_hat = outs[l]["x_hat"].cpu().clamp_(0, 1)
             p_here = psnr_of(x, x_hat)
             b_here = rows[i * 13 + l]["bpp"]
-            assert b_here == bpp_of(d["strings"], 1, gi["H"], gi["W"]) and abs(rows[i * 13 + l]["psnr"] - p_here) < 1e-9
+            assert b_here == bpp_of(d["strings"], 1, gi["H"], gi["W"]) and abs(rows[i * 13 + l]["psnr"] - p_here) < 1e-5   # (the harness reduces the mean on the GPU)
             if cmp_["flip_free_images"]:
                 n_ff += 1
                 assert b_here == lv["bpp"] and abs(p_here - lv["psnr"]) <= NORTH_STAR_PSNR_TOL_DB

@@ -9,21 +9,21 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_stats_default $O/prof_stats_1lane $O/prof_stats_1lane_r01kernel $O/pmc_FETCH $O/pmc_WRITE $O/prof_stage $O/pmc_clk_serial
 # serial form: one lane, one stream, no pipelining inside the codec and no encoder / decoder overlap -- a launch's duration is its own
 SER="PC_LANES=1 PC_DUAL_STREAM=0 PC_PIPELINE=0"
-timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_default -o run -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_stats_default.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_default -o run -- python3 $R/bench.py --steps 10 --warmup 2 --lean > $O/prof_stats_default.log 2>&1 || exit 1
 echo "default stats done"
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --overlap 0 > $O/prof_stats_1lane.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 > $O/prof_stats_1lane.log 2>&1 || exit 1
 echo "1lane stats done"
 # the round-1 kernel and tile choice on the same box, same serial form (cross-box comparisons carry +-5 %)
-env $SER PC_CONV_KERN=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane_r01kernel -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --overlap 0 > $O/prof_stats_1lane_r01kernel.log 2>&1 || exit 1
+env $SER PC_CONV_KERN=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane_r01kernel -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 > $O/prof_stats_1lane_r01kernel.log 2>&1 || exit 1
 echo "1lane r01-kernel stats done"
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_FETCH -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --overlap 0 > $O/pmc_FETCH.log 2>&1 || exit 1
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_WRITE -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --overlap 0 > $O/pmc_WRITE.log 2>&1 || exit 1
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_clk_serial -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --overlap 0 > $O/pmc_clk_serial.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_FETCH -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_FETCH.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_WRITE -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_WRITE.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_clk_serial -o run -- python3 $R/bench.py --steps 2 --warmup 1 --lean --overlap 0 > $O/pmc_clk_serial.log 2>&1 || exit 1
 echo "pmc done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_stage -o run -- python3 $R/tools/stage_bench.py 256 > $O/prof_stage.log 2>&1 || exit 1
 cd $R
 # per-launch shapes and HIP-event times of the serial profile step (the per-shape table of DESIGN.md section 6), no profiler attached
-PC_PROFILE_CSV=$P/${TAG}_conv_launches_bench_b32.csv timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $O/prof_launches.log 2>&1 || exit 1
+PC_PROFILE_CSV=$P/${TAG}_conv_launches_bench_b32.csv timeout -k 10 300 python3 bench.py --steps 10 --warmup 2 --lean > $O/prof_launches.log 2>&1 || exit 1
 grep -h '^{' $O/prof_launches.log | tail -1 > $P/${TAG}_bench_default_no_profiler.json
 python3 tools/rocpd_stats.py $O/prof_stats_default > $P/${TAG}_kernel_stats_bench_b32_default.csv
 python3 tools/rocpd_stats.py $O/prof_stats_1lane > $P/${TAG}_kernel_stats_bench_b32_1lane.csv
