@@ -19,12 +19,13 @@
 // K -- so results are bit-identical for every tile shape, batch size and device, and equal
 // to oracle/pc_oracle.c:orc_conv_nhwc.
 //
-// Two kernels: conv_igemm_dma_kernel (further down; weight layout 1) serves every layer whose Cin is a multiple of 16 and
+// Two kernels: conv_igemm_uni_kernel (further down; weight layout 1) serves every layer whose Cin is a multiple of 16 and
 // Cout > 4 -- all but two; conv_igemm_kernel (next; weight layout 0) is the plain form kept for the 3-channel input layer
 // (element gather from NCHW) and as the generic fallback behind pc_conv2d_nhwc: 256 threads = 4 waves, block tile BM x BN,
 // K-chunk 16, each wave owns TM x TN MFMA tiles of 32x32 (16 accumulator VGPRs each); A/B chunks are register-staged
 // global->LDS with double buffering (one barrier per chunk); LDS images are k-major ([k][m] / [k][n]) so every ds_read_b32
-// of an MFMA operand is bank-conflict-free.
+// of an MFMA operand is bank-conflict-free.  (Round 1's wave-specialised kernel with separate loader waves, the A/B baseline of
+// round 2, was removed in round 3: its measurements are in profiles/r01_*, r02_z_*_r01kernel_same_box.*.)
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
@@ -281,22 +282,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 
 
 // ------------------------------------------------------------------------------------------
-// Wave-specialised kernel with LDS-DMA loaders (weight layout 1).  Ablations of the kernel above
-// (tools/conv_tune.py, PC_CONV_DBG): loader-only 111 us + MFMA-only 165 us ~= full 246 us on the
-// 8192x224x4608 slice-chain GEMM -- loader instructions and f32 MFMAs do not overlap on a SIMD, so
-// every loader instruction costs matrix time.  Here the loader waves issue only LDS-DMA loads
-// (`buffer_load_dwordx4 ... lds`: 16 B per lane straight into LDS, no VGPR staging, no ds_write) plus a
-// few scalar ops; the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE
-// address (LDS-DMA writes lane-linearly), read back conflict-free with ds_read_b128; weights are
-// pre-packed [tap][Cout][Cin] (K contiguous per output channel).  The contract's chain order inside an
-// aligned group of 8 k (0,4,1,5,2,6,3,7) is exactly what the MFMA computes when lanes 0-31 hold the
-// group's first 16-byte quad and lanes 32-63 its second: per 4 MFMAs an MFMA wave issues 2
-// ds_read_b128 and no VALU (an earlier k-ascending contract needed 3 reads + 4 v_cndmask per 4 MFMAs:
-// 22 % slower, PC_CONV_DBG ablation in profiles/r01_tune_tune12.log).
-//
-// Template: K-chunk BK, S LDS stages (the loaders keep S-1 chunks in flight behind counted
-// `s_waitcnt vmcnt(N)`; raw `s_barrier`s, which do not drain VMEM, hand a landed stage to the MFMA waves),
-// WM x WN MFMA waves of one 32x32 tile each (block tile 32*WM x 32*WN) and as many loader waves.
+// LDS-DMA implicit GEMM (weight layout 1): shared pieces.  `buffer_load_dwordx4 ... lds` moves 16 B per lane straight into LDS
+// (no VGPR staging, no ds_write); the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE address (LDS-DMA
+// writes lane-linearly), read back conflict-free with ds_read_b128; weights are pre-packed [tap][Cout][Cin] (K contiguous per
+// output channel).  The contract's chain order inside an aligned group of 8 k (0,4,1,5,2,6,3,7) is exactly what the MFMA computes
+// when lanes 0-31 hold the group's first 16-byte quad and lanes 32-63 its second: per 4 MFMAs a wave issues 2 ds_read_b128 and no
+// VALU (an earlier k-ascending contract needed 3 reads + 4 v_cndmask per 4 MFMAs: 22 % slower, profiles/r01_tune_tune12.log).
 // ------------------------------------------------------------------------------------------
 // diagnostic build only (PC_CONV_DBG & 64): per-block cycle sums of the K-loop / prologue / epilogue phases, [block][16]
 __device__ unsigned long long pc_dbg_stamps[8192][16];
@@ -322,354 +313,6 @@ template <int NI, int MAXC> __device__ __forceinline__ void pc_wait_chunks(int c
 }
 
 struct pc_run { const float* a_base; const float* w_base; int ld, nch, tap, pad; };   // one (tap, input segment) of the K loop
-
-template <int BK, int S, int WM, int WN, bool STAMPS, bool SQ>
-__global__ __launch_bounds__(128 * WM * WN) void conv_igemm_dma_kernel(const pc_conv_params p)
-{
-    constexpr int BM = 32 * WM, BN = 32 * WN, KQ = BK / 4;
-    constexpr int NMW = WM * WN;                          // MFMA waves; as many loader waves
-    constexpr int NLT = NMW * 64;                         // loader threads
-    constexpr int A_PIECES = BM * KQ, B_PIECES = BN * KQ, STAGE = A_PIECES + B_PIECES;
-    constexpr int AIN = A_PIECES / NLT, BIN = B_PIECES / NLT;       // DMA instructions per loader thread per chunk
-    constexpr int NI = AIN + BIN;
-    static_assert(AIN >= 1 && BIN >= 1 && A_PIECES % NLT == 0 && B_PIECES % NLT == 0, "tile / loader mismatch");
-    static_assert((S - 2) * NI < 64, "vmcnt range");
-#if defined(__HIP_DEVICE_COMPILE__)   // the body uses amdgcn-only types (buffer descriptors): the host pass only needs the launch stub
-    extern __shared__ float4 smem[];                      // S stages, then the run table (launch_dma sizes it)
-
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;   // wave index in an SGPR
-    unsigned long long t_entry = 0;
-    if (STAMPS) t_entry = __builtin_amdgcn_s_memtime();
-    // XCD-aware tile order (1-D grid).  Workgroups are handed to the 8 XCDs round-robin in dispatch order and every XCD has its
-    // own 4 MB L2.  With the plain (x = M tile, y = N tile) grid the N tiles / phases / groups that read the SAME activation tile
-    // ran thousands of workgroups apart and neighbouring M tiles (which share input rows through the taps) landed on different
-    // XCDs: PMC showed 3.7 GB (x2 by the gfx950 correction) fetched for the 0.4 GB input of the largest layer.  Here XCD x owns the
-    // contiguous band of M tiles [x*mpx, (x+1)*mpx) and walks it with (N tile, phase/group) fastest.
-    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
-    const int mpx = (MT + 7) >> 3;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int m_local = slot / (NT * NZ), nz = slot - m_local * (NT * NZ);
-    const int m_tile = xcd * mpx + m_local;
-    if (m_tile >= MT) return;                             // padding of the last band (whole workgroup, before any barrier)
-    const int zsel = nz / NT, n_tile = nz - zsel * NT;
-    int phase = zsel;
-    const float* seg0_ptr = p.seg[0].ptr;
-    const float* wbase = p.w;
-    const float* bias = p.bias;
-    float* outp = p.out;
-    if (p.ngroup == 2 && zsel == 1) { phase = 0; seg0_ptr = p.g1_seg0; wbase = p.g1_w; bias = p.g1_bias; outp = p.g1_out; }
-    if (p.ngroup == 2) phase = 0;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
-    const int T = p.ntap[phase];
-    const int HoWo = p.Ho * p.Wo;
-    int chunks_per_tap = 0;
-    for (int s = 0; s < p.nseg; ++s) chunks_per_tap += (p.seg[s].nch + BK - 1) / BK;
-    const int nchunks = T * chunks_per_tap;
-    const int blk = blockIdx.x;
-
-    if (wave >= NMW) {
-        // ------------------------------------------------------------------ loader waves
-        // The loaders issue ~30 instructions per chunk; at default priority they only got an issue slot about once per
-        // MFMA of their SIMD partner (stamps: loader issue time == MFMA phase + 200 cycles).  Highest priority lets them
-        // slip their few instructions in as soon as they are ready.
-        __builtin_amdgcn_s_setprio(3);
-        const int lw = wave - NMW;
-        // Addressing: buffer (V#) form of the LDS-DMA load.  Per run the loaders hold two wave-uniform buffer descriptors
-        // (activations: base = segment pointer + tap offset + the tile's first pixel; weights: base = the run's weight block + the
-        // tile's first row), every lane keeps a 32-bit byte offset that is constant for the whole run, and the position inside the
-        // run is ONE scalar offset advanced per chunk.  A lane whose piece does not exist (tap outside the image, row beyond M or
-        // Cout, channel beyond the segment) carries an out-of-range offset: the hardware then writes zeros into LDS (checked on
-        // MI355X), which replaces the zero page and the per-DMA 64-bit select / pointer-increment VALU work of the `global_load_lds`
-        // form -- the loader waves were the long pole of every chunk (stamps: issue 1500-2700 cycles vs 1300-2000 of MFMA work).
-        constexpr int OOB = (int)0x80000000;               // >= num_records (0x7fffffff): reads as zero
-        int a_q[AIN], a_rel[AIN]; uint32_t a_mask[AIN];
-        // the tile's first pixel (row m0 of the GEMM); rows of a tile have increasing pixel indices, so offsets relative to it are
-        // small and non-negative whatever the tensor size (a 32-bit offset from the tensor start would overflow on Config 4)
-        int64_t pix0;
-        if (p.rowtab) {
-            // rows -> (input pixel, tap mask) from the table cached per layer geometry (pc_conv_launch): two loads per row instead of
-            // two integer divisions and a loop over the taps.  Any instruction of this prologue costs ~40 cycles while other
-            // workgroups' MFMA waves saturate the SIMD, and the first workgroups' prologue is exposed on every one of the 543
-            // dependent launches of a step (stamps: 10 k cycles at 9 taps, 45 k at 25 before).
-            pix0 = p.rowtab[m0];
-#pragma unroll
-            for (int i = 0; i < AIN; ++i) {
-                const int pa = (lw * AIN + i) * 64 + lane;
-                const int row = pa / KQ, slot = pa % KQ;
-                a_q[i] = slot ^ pc_swz<KQ>(row);
-                const int m = m0 + row;
-                const bool ok = m < p.M;
-                a_rel[i] = ok ? p.rowtab[m] - (int)pix0 : 0;
-                a_mask[i] = (ok && !(p.dbg & 4)) ? (uint32_t)p.rowtab[(size_t)(1 + phase) * p.M + m] : 0u;
-            }
-        } else if (p.ident_rows) {
-            // 1x1 stride-1 layers (linear, GDN, the ResidualUnit 1x1s): row m of the GEMM is input pixel m, the single tap is always valid
-            pix0 = m0;
-#pragma unroll
-            for (int i = 0; i < AIN; ++i) {
-                const int pa = (lw * AIN + i) * 64 + lane;
-                const int row = pa / KQ, slot = pa % KQ;
-                a_q[i] = slot ^ pc_swz<KQ>(row);
-                a_rel[i] = row;
-                a_mask[i] = (m0 + row < p.M && !(p.dbg & 4)) ? 1u : 0u;
-            }
-        } else {
-            {
-                const int b = m0 / HoWo, r = m0 - b * HoWo;
-                const int oy = r / p.Wo, ox = r - oy * p.Wo;
-                pix0 = ((int64_t)b * p.H + (int64_t)oy * p.stride) * p.W + (int64_t)ox * p.stride;
-            }
-#pragma unroll
-            for (int i = 0; i < AIN; ++i) {
-                const int pa = (lw * AIN + i) * 64 + lane;
-                const int row = pa / KQ, slot = pa % KQ;
-                a_q[i] = slot ^ pc_swz<KQ>(row);
-                const int m = m0 + row;
-                const bool ok = m < p.M;
-                const int mm = ok ? m : m0;
-                const int b = mm / HoWo, r = mm - b * HoWo;
-                const int oy = r / p.Wo, ox = r - oy * p.Wo;
-                const int iy0 = oy * p.stride, ix0 = ox * p.stride;
-                a_rel[i] = (int)((((int64_t)b * p.H + iy0) * p.W + ix0) - pix0);
-                uint32_t mask = 0;
-                for (int t = 0; t < T; ++t) {
-                    const int iy = iy0 + p.dy[phase][t], ix = ix0 + p.dx[phase][t];
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mask |= 1u << t;
-                }
-                a_mask[i] = (ok && !(p.dbg & 4)) ? mask : 0u;   // ablation 4: every piece out of range (no L2 traffic, same instruction stream)
-            }
-        }
-        int b_q[BIN], b_off[BIN];
-#pragma unroll
-        for (int i = 0; i < BIN; ++i) {
-            const int pb = (lw * BIN + i) * 64 + lane;
-            const int row = pb / KQ, slot = pb % KQ;
-            b_q[i] = slot ^ pc_swz<KQ>(row);
-            b_off[i] = (n0 + row < p.Cout && !(p.dbg & 4)) ? (row * p.Cin + 4 * b_q[i]) * 4 : OOB;
-        }
-        // The K loop walks "runs" = (tap, segment) pairs.  In-kernel stamps (PC_CONV_DBG=64, profiles/r01_tune_tune14.log)
-        // showed the loaders spending 1700-4700 cycles per chunk ISSUING 4-8 DMAs -- dependent scalar loads of the
-        // tap / segment tables from the kernel-argument segment plus 64-bit address arithmetic -- while the MFMA waves
-        // idled at the barrier 40-55 % of their time.  The run descriptors are therefore built once into LDS and only a run
-        // boundary (every nch/BK chunks) touches the descriptor table.
-        unsigned long long t_masks = 0, t_table = 0;
-        if (STAMPS) t_masks = __builtin_amdgcn_s_memtime();
-        pc_run* runs = reinterpret_cast<pc_run*>(smem + S * STAGE);
-        const int nruns = T * p.nseg;
-        for (int r = threadIdx.x - NLT; r < nruns; r += NLT) {
-            const int t = r / p.nseg, sg = r - t * p.nseg;
-            int cbase = 0;
-            for (int q = 0; q < sg; ++q) cbase += p.seg[q].nch;
-            pc_run d;
-            d.ld = p.seg[sg].ld; d.nch = p.seg[sg].nch; d.tap = t; d.pad = 0;
-            d.a_base = (sg == 0 ? seg0_ptr : p.seg[sg].ptr) + (int64_t)(p.dy[phase][t] * p.W + p.dx[phase][t]) * d.ld;
-            d.w_base = wbase + (int64_t)p.wtap[phase][t] * p.Cout * p.Cin + cbase;
-            runs[r] = d;
-        }
-        __syncthreads();                                   // run table visible (MFMA waves execute the matching barrier)
-        if (STAMPS) t_table = __builtin_amdgcn_s_memtime();
-        const uint32_t runs_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)runs;
-        uint32_t ra_lo = 0, ra_hi = 0, rb_lo = 0, rb_hi = 0;      // the two descriptors' base addresses (wave-uniform)
-        int a_off[AIN];
-        int run = 0, c_left = 0, koff = 0;
-        auto enter_run = [&](int r) {
-            // The descriptor is read with hand-written ds_read_b128: behind a plain LDS load hipcc places `s_waitcnt vmcnt(0)`
-            // (it must assume the read aliases an in-flight LDS-DMA), which would drain the prefetch pipeline at every run
-            // boundary.  The table is written once, before the first DMA, and no DMA targets it.  readfirstlane: the values are
-            // wave-uniform, but an asm result lives in VGPRs and would make every later branch / descriptor look divergent.
-            u32x4 lo, hi;
-            asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(lo), "=&v"(hi) : "v"(runs_lds + (uint32_t)r * 32u) : "memory");
-            const uint64_t pa = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.y) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.x);
-            const uint64_t pw = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)lo.w) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo.z);
-            const int d_ld = __builtin_amdgcn_readfirstlane((int)hi.x), d_nch = __builtin_amdgcn_readfirstlane((int)hi.y);
-            const int d_tap = __builtin_amdgcn_readfirstlane((int)hi.z);
-            const float* d_a = reinterpret_cast<const float*>(pa) + pix0 * d_ld;
-            const float* d_w = reinterpret_cast<const float*>(pw) + (int64_t)n0 * p.Cin;
-            ra_lo = (uint32_t)(uintptr_t)d_a; ra_hi = (uint32_t)((uintptr_t)d_a >> 32);
-            rb_lo = (uint32_t)(uintptr_t)d_w; rb_hi = (uint32_t)((uintptr_t)d_w >> 32);
-            c_left = d_nch; koff = 0;
-#pragma unroll
-            for (int i = 0; i < AIN; ++i) a_off[i] = ((a_mask[i] >> d_tap) & 1u) ? (a_rel[i] * d_ld + 4 * a_q[i]) * 4 : OOB;
-        };
-        enter_run(0);
-        auto issue = [&](int stage) {
-            float4* lds_a = smem + stage * STAGE + lw * AIN * 64;
-            float4* lds_b = smem + stage * STAGE + A_PIECES + lw * BIN * 64;
-            // descriptors rebuilt from readfirstlane'd halves: hipcc must SEE they are scalar, or it wraps every load in a waterfall loop
-            auto mk = [](uint32_t lo, uint32_t hi) {
-                const uint64_t a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)lo);
-                return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(a), 0, 0x7fffffff, 0x00020000);
-            };
-            const __amdgpu_buffer_rsrc_t rsrc_a = mk(ra_lo, ra_hi), rsrc_b = mk(rb_lo, rb_hi);
-            if (c_left >= BK) {
-#pragma unroll
-                for (int i = 0; i < AIN; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16, a_off[i], koff, 0, 0);
-#pragma unroll
-                for (int i = 0; i < BIN; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16, b_off[i], koff, 0, 0);
-            } else {                                        // last, partial chunk of a segment whose channel count is not a multiple of BK
-#pragma unroll
-                for (int i = 0; i < AIN; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(lds_a + i * 64), 16,
-                                                             4 * a_q[i] < c_left ? a_off[i] : OOB, koff, 0, 0);
-#pragma unroll
-                for (int i = 0; i < BIN; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(lds_b + i * 64), 16,
-                                                             4 * b_q[i] < c_left ? b_off[i] : OOB, koff, 0, 0);
-            }
-            koff += BK * 4;
-            c_left -= BK;
-            if (c_left <= 0 && ++run < nruns) enter_run(run);
-        };
-        // chunk c lives in stage c % S; chunks c+1 .. c+S-1 are in flight while the MFMA waves work on chunk c
-        int issued = 0, st_issue = 0;
-        for (; issued < S - 1 && issued < nchunks; ++issued) { issue(st_issue); st_issue = st_issue + 1 == S ? 0 : st_issue + 1; }
-        pc_wait_chunks<NI, S - 2>(issued - 1);             // chunk 0 landed
-        __builtin_amdgcn_s_barrier();
-        if (STAMPS && wave == NMW && lane == 0 && blk < 8192) {
-            pc_dbg_stamps[blk][12] = t_masks - t_entry; pc_dbg_stamps[blk][13] = t_table - t_masks;
-            pc_dbg_stamps[blk][14] = __builtin_amdgcn_s_memtime() - t_table;
-        }
-        unsigned long long s_issue = 0, s_dma = 0, s_bar = 0;
-        for (int c = 0; c < nchunks; ++c) {
-            unsigned long long t0 = 0, t1 = 0, t2 = 0;
-            if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
-            // stage (c+S-1) % S was last read while computing chunk c-1: the barrier that ended iteration c-1 released it
-            if (issued < nchunks && !(p.dbg & 2)) { issue(st_issue); st_issue = st_issue + 1 == S ? 0 : st_issue + 1; ++issued; }
-            if (STAMPS) t1 = __builtin_amdgcn_s_memtime();
-            pc_wait_chunks<NI, S - 2>(issued - (c + 2));   // chunk c+1 landed (those after it may still be in flight)
-            if (STAMPS) t2 = __builtin_amdgcn_s_memtime();
-            __builtin_amdgcn_s_barrier();
-            if (STAMPS) { s_issue += t1 - t0; s_dma += t2 - t1; s_bar += __builtin_amdgcn_s_memtime() - t2; }
-        }
-        if (STAMPS && wave == NMW && lane == 0 && blk < 8192) {
-            pc_dbg_stamps[blk][0] = s_issue; pc_dbg_stamps[blk][1] = s_dma; pc_dbg_stamps[blk][2] = s_bar; pc_dbg_stamps[blk][3] = nchunks;
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------- MFMA waves
-    if (p.dbg & 512) {                                     // experiment: distinct issue priorities for the workgroups sharing a CU
-        switch ((blockIdx.x >> 8) & 3) {
-        case 0: __builtin_amdgcn_s_setprio(2); break;
-        case 1: __builtin_amdgcn_s_setprio(1); break;
-        default: __builtin_amdgcn_s_setprio(0); break;
-        }
-    }
-    const int wm = wave / WN, wn = wave % WN;
-    const int half = lane >> 5, l31 = lane & 31;
-    const int am = wm * 32 + l31, bn = wn * 32 + l31;      // this lane's A row / B row inside the block tile
-    const int a_swz = pc_swz<KQ>(am), b_swz = pc_swz<KQ>(bn);
-    // column tiles that lie outside Cout (N tails: 224, 176, 160, 96, 32 ...) issue no MFMAs
-    const bool live = (n0 + wn * 32 < p.Cout) && !(p.dbg & 1);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-    auto compute = [&](int stage) {
-        const float4* A = smem + stage * STAGE + am * KQ;
-        const float4* Bp = smem + stage * STAGE + A_PIECES + bn * KQ;
-        constexpr int NG = BK / 8;                          // groups of 4 MFMA steps (8 k)
-        float4 va[2], vb[2];
-        // group g = 8 consecutive k = two 16-byte quads; lanes 0-31 take quad 2g, lanes 32-63 quad 2g+1, for A and B alike:
-        // MFMA step s then multiplies k = 8g+s (first) and k = 8g+4+s (second) -- the contract's in-group order
-        // 0,4,1,5,2,6,3,7 -- with one ds_read_b128 per operand per 4 MFMAs and no VALU at all
-        va[0] = A[(half) ^ a_swz]; vb[0] = Bp[(half) ^ b_swz];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) { va[(g + 1) & 1] = A[(2 * (g + 1) + half) ^ a_swz]; vb[(g + 1) & 1] = Bp[(2 * (g + 1) + half) ^ b_swz]; }
-            __builtin_amdgcn_sched_barrier(0);
-            float4 x = va[g & 1];
-            const float4 y = vb[g & 1];
-            if (SQ) { x.x *= x.x; x.y *= x.y; x.z *= x.z; x.w *= x.w; }     // GDN feeds x^2 (gdn.py:56)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, y.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, y.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, y.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, y.w, acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    __syncthreads();                                       // run table built by the loaders
-    __builtin_amdgcn_s_barrier();                          // chunk 0 landed
-    unsigned long long s_cmp = 0, s_bar = 0, t_loop = 0, t_epi = 0, r_loop = 0, r_epi = 0;
-    if (STAMPS) { t_loop = __builtin_amdgcn_s_memtime(); r_loop = __builtin_amdgcn_s_memrealtime(); }
-    int st = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        unsigned long long t0 = 0, t1 = 0;
-        if (STAMPS) t0 = __builtin_amdgcn_s_memtime();
-        if (live) compute(st);
-        st = st + 1 == S ? 0 : st + 1;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's reads of the stage are complete before it is released
-        if (STAMPS) { __builtin_amdgcn_sched_barrier(0); t1 = __builtin_amdgcn_s_memtime(); }
-        __builtin_amdgcn_s_barrier();
-        if (STAMPS) { s_cmp += t1 - t0; s_bar += __builtin_amdgcn_s_memtime() - t1; }
-    }
-    if (STAMPS && lane == 0 && blk < 8192) { pc_dbg_stamps[blk][4 + (wave & 1) * 2] = s_cmp; pc_dbg_stamps[blk][5 + (wave & 1) * 2] = s_bar; }
-    if (STAMPS) { t_epi = __builtin_amdgcn_s_memtime(); r_epi = __builtin_amdgcn_s_memrealtime(); }
-    if (!live) return;
-    const int n = n0 + wn * 32 + l31;
-    const float bv = (bias && n < p.Cout) ? bias[n] : 0.0f;
-    if (p.dense_out) {
-        // layers storing a plain NHWC(-strided) tensor on the GEMM's own pixel grid: the output pixel index is the GEMM row, no
-        // div/mod.  The epilogue's aux tiles (residual / gate / GDN input / LRP base: 32 rows x 32 columns per wave) are fetched with
-        // four LDS-DMA loads per tile into the now idle stage buffers and read back from LDS: one memory latency per wave instead
-        // of a chain of 16 dependent global loads (the epilogue of the 1x1 layers was 3x its VALU and HBM bounds), and no extra
-        // VGPRs (holding the 16 values in registers cost occupancy: profiles/r01_j_*).
-        const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
-        float* tile = reinterpret_cast<float*>(smem + wave * 512);            // 2 x 4 KB per MFMA wave (S * STAGE >= 2048 float4)
-        if (u0) {
-            constexpr int OOBE = (int)0x80000000;
-            const int mb = m0 + wm * 32, nb = n0 + wn * 32;
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                if (a == 1 && !u1) break;
-                const float* src = (a == 0 ? p.aux0 : p.aux1) + (int64_t)mb * (a == 0 ? p.ld0 : p.ld1) + nb;
-                const int ld = a == 0 ? p.ld0 : p.ld1;
-                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int piece = i * 64 + lane, row = piece >> 3, cq = piece & 7;
-                    const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + i * 256), 16,
-                                                             ok ? (row * ld + 4 * cq) * 4 : OOBE, 0, 0, 0);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        if (n >= p.Cout) return;                              // (only now: the tile loads above need the whole wave)
-        for (int r = 0; r < 16; ++r) {
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int m = m0 + wm * 32 + row;
-            if (m >= p.M) continue;
-            float v = acc[r];
-            if (bias) v = v + bv;
-            const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
-            outp[(int64_t)m * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
-        }
-    } else
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-        const int m = m0 + wm * 32 + row;
-        if (m >= p.M || n >= p.Cout) continue;
-        const int b = m / HoWo, rr = m - b * HoWo;
-        const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-        const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-        float v = acc[r];
-        if (bias) v = v + bv;
-        int nn = n, YY = Y, XX = X;
-        if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
-        const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
-        v = epilogue_value(p, v, pix, nn);
-        outp[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
-    }
-    if (STAMPS && wave == 0 && lane == 0 && blk < 8192) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        pc_dbg_stamps[blk][8] = t_loop - t_entry; pc_dbg_stamps[blk][9] = __builtin_amdgcn_s_memtime() - t_epi;
-        pc_dbg_stamps[blk][10] = t_epi - t_loop; pc_dbg_stamps[blk][11] = r_epi - r_loop;   // in-kernel clock = [10]/[11] x 100 MHz
-    }
-#endif
-}
 
 // ------------------------------------------------------------------------------------------
 // Unified kernel (round 2): every wave loads AND multiplies; no loader waves.
@@ -719,7 +362,11 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     }
     unsigned long long tl[4] = {0, 0, 0, 0};               // DBG & 64: timeline of this wave in s_memrealtime ticks (100 MHz, chip-wide)
     if (DBG & 64) tl[0] = __builtin_amdgcn_s_memrealtime();
-    // XCD-aware tile order: see conv_igemm_dma_kernel
+    // XCD-aware tile order (1-D grid).  Workgroups are handed to the 8 XCDs round-robin in dispatch order and every XCD has its own
+    // 4 MB L2.  With a plain (x = M tile, y = N tile) grid the N tiles / phases / groups that read the SAME activation tile ran thousands
+    // of workgroups apart and neighbouring M tiles (which share input rows through the taps) landed on different XCDs: PMC showed 3.7 GB
+    // (x2 by the gfx950 correction) fetched for the 0.4 GB input of the largest layer.  Here XCD x owns the contiguous band of M tiles
+    // [x*mpx, (x+1)*mpx) and walks it with (N tile, phase/group) fastest.
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     const int mpx = (MT + 7) >> 3;
     const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -876,7 +523,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
 #pragma unroll
         for (int i = 0; i < BIN; ++i) b_off[i] = OOB;
     }
-    auto enter_run = [&](int r) {                          // hand-written LDS reads: see conv_igemm_dma_kernel
+    auto enter_run = [&](int r) {                          // hand-written LDS reads: behind a plain LDS load hipcc places s_waitcnt vmcnt(0) (it must assume the read aliases an in-flight LDS-DMA)
         u32x4 lo, hi;
         asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)"
                      : "=&v"(lo), "=&v"(hi) : "v"(runs_lds + (uint32_t)r * 32u) : "memory");
@@ -1129,86 +776,217 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     };
 
     // ---- epilogue, tile by tile
+    // Round 3.  The first form of this epilogue was a ROLLED loop over the 16 accumulator rows of a lane (hipcc kept it rolled: dynamic
+    // VGPR indexing through s_set_gpr_idx, the switch over the epilogue kind evaluated per element, two 64-bit multiplies of address
+    // arithmetic and -- on the strided / PixelShuffle outputs -- two integer divisions per element): ~740 instructions per element, 6-10 us
+    // per workgroup on the short-K layers where the K loop itself takes 3-8 us (tools/conv_timeline.py, profiles/r03_d_*).  Now:
+    //  * the epilogue kind is a compile-time constant of the code that runs (one dispatch per workgroup);
+    //  * lanes 0-31 compute the 32 rows' output offsets ONCE per tile (row table of the layer, or one division pair per ROW for the
+    //    strided / PixelShuffle outputs) and park them in LDS; every lane fetches its 16 rows' offsets with four ds_read_b128;
+    //  * the 16 rows are unrolled (accumulators addressed directly) and leave through buffer stores relative to the tile's first
+    //    row: 32-bit offsets, rows beyond M dropped by the hardware's range check.
+    // Same arithmetic on the same values in the same order: the bits do not move.
     if (nlive == 0) { stamp_out(); return; }
     const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
-    // aux tiles of the tile being finished, 4 KB each: aux0 alone -> 4 KB per wave, aux0 + aux1 -> 8 KB per wave (launch_uni sizes the
-    // allocation for that when the stages are smaller)
-    float* tile = reinterpret_cast<float*>(smem) + wave * (u1 ? 2048 : 1024);
+    // LDS: the stages are free now.  Aux tiles of the tile being finished, 4 KB each: aux0 alone -> 4 KB per wave, aux0 + aux1 -> 8 KB per
+    // wave at the start of the allocation; behind them (and behind the stages, whichever is larger: launch_uni sizes it) 64 words per
+    // wave of row tables: [0..31] byte offset of the row's output pixel relative to the tile's first, [32..63] its aux pixel index.
+    const uint32_t epi_bytes = !p.dense_out ? 0u : (u1 ? 32768u : (u0 ? 16384u : 0u));
+    const uint32_t tab_byte0 = (uint32_t)(S * STAGE * 16) > epi_bytes ? (uint32_t)(S * STAGE * 16) : epi_bytes;
+    uint32_t* rowtab_lds = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(smem) + tab_byte0) + wave * 64;
+    const uint32_t rowtab_lds_addr = smem_lds + tab_byte0 + (uint32_t)wave * 256u;
+    // (the unrolled form is instantiated for the one-tile waves only -- every default instantiation; the two- and four-tile waves, reachable
+    // through PC_CONV_TM / PC_CONV_TN for the bit-invariance runs, keep the generic loop: 24 more epilogue bodies per tile otherwise)
+    const bool fast = TM * TN == 1 && p.out_sc == 1 && (p.dense_out || !u0);
+    // (dynamic indexing of the kernel-argument struct from inside a lambda makes hipcc copy the whole struct to scratch: hoisted)
+    const int ooy_ph = p.ooy[phase], oox_ph = p.oox[phase];
+    const float* const aux0_p = p.aux0; const float* const aux1_p = p.aux1;
+    const int ld0_v = p.ld0, ld1_v = p.ld1, epi_v = p.epi;
+    // every kernel argument the tile code below needs, as plain locals: the lambdas must not touch `p` (with the 24 inlined epilogue bodies
+    // referring to it hipcc gave up promoting the argument struct and copied all 1.6 KB of it to scratch at kernel entry)
+    const int e_Cout = p.Cout, e_M = p.M, e_dense = p.dense_out, e_perm = p.rowperm, e_ps = p.pixel_shuffle, e_osy = p.osy, e_osx = p.osx, e_Wo = p.Wo,
+              e_outH = p.outH, e_outW = p.outW;
+    const int64_t e_sx = p.out_sx, e_sy = p.out_sy, e_sb = p.out_sb, e_sc = p.out_sc;
+    const int* const e_rowtab = p.rowtab;
+    auto slow_tile = [&](auto i_tag, auto j_tag) __attribute__((always_inline)) {   // generic form: any output strides, aux tensors read from global memory
+        constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+        const int mb = m0 + wm * 32 * TM + i * 32, nb = n0 + (wn * TN + j) * 32;
+        const int n = nb + l31;
+        const float bv = (bias && n < e_Cout) ? bias[n] : 0.0f;
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int m = mb + row;
+            if (m >= e_M || n >= e_Cout) continue;
+            int64_t opix;
+            float v = acc[i][j][r];
+            if (bias) v = v + bv;
+            if (e_dense) {
+                opix = e_perm ? (int64_t)e_rowtab[m] : (int64_t)m;
+                v = epilogue_apply(epi_v, v, u0 ? aux0_p[opix * ld0_v + n] : 0.0f, u1 ? aux1_p[opix * ld1_v + n] : 0.0f);
+                outp[opix * e_sx + (int64_t)n * e_sc] = v;
+                continue;
+            }
+            const int b = m / HoWo, rr = m - b * HoWo;
+            const int oy = rr / e_Wo, ox = rr - oy * e_Wo;
+            const int Y = oy * e_osy + ooy_ph, X = ox * e_osx + oox_ph;
+            int nn = n, YY = Y, XX = X;
+            if (e_ps) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
+            const int64_t pix = ((int64_t)b * e_outH + YY) * e_outW + XX;
+            v = epilogue_apply(epi_v, v, u0 ? aux0_p[pix * ld0_v + nn] : 0.0f, u1 ? aux1_p[pix * ld1_v + nn] : 0.0f);
+            outp[(int64_t)b * e_sb + (int64_t)YY * e_sy + (int64_t)XX * e_sx + (int64_t)nn * e_sc] = v;
+        }
+    };
+    // DIRECT (compile-time in each copy): dense output on the GEMM's own pixel grid with rows in pixel order -- the output pixel of tile row
+    // `row` is mb + row, no table needed: the row part of a store's offset is a scalar multiple of the pixel stride.  Otherwise (permuted
+    // rows; strided / PixelShuffle outputs) lanes 0-31 compute the 32 rows' offsets once per tile, park them in LDS, and every lane picks
+    // up the four rows of an accumulator quad with one ds_read_b128.
+    auto fast_tile = [&](auto epi_tag, auto direct_tag, auto i_tag, auto j_tag) __attribute__((always_inline)) {
+        constexpr int EPI = decltype(epi_tag)::value, i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+        constexpr bool DIRECT = decltype(direct_tag)::value;
+        constexpr bool U0 = EPI == PC_EPI_RES_GELU || EPI == PC_EPI_RES || EPI == PC_EPI_GATE || EPI == PC_EPI_GDN || EPI == PC_EPI_IGDN || EPI == PC_EPI_LRP ||
+                            EPI == PC_EPI_LRP_ADD || EPI == PC_EPI_LEAKY_RES;
+        constexpr bool U1 = EPI == PC_EPI_GATE || EPI == PC_EPI_LRP_ADD;
+        float* tile = reinterpret_cast<float*>(smem) + wave * (U1 ? 2048 : 1024);
+        const int mb = m0 + wm * 32 * TM + i * 32, nb = n0 + (wn * TN + j) * 32;
+        const int n = nb + l31;
+        const float bv = (bias && n < e_Cout) ? bias[n] : 0.0f;
+        int64_t off0 = 0;                                             // element offset of the tile's first output pixel (wave-uniform)
+        if (DIRECT) off0 = (int64_t)mb * e_sx;
+        else {
+            // row table of this tile: every lane computes row l31's entry (both halves alike), lanes 0-31 write it
+            const int m = mb + l31;
+            const bool ok = m < e_M;
+            int64_t off;                                              // element offset of the row's output pixel, channel 0
+            int pixrel = l31;                                         // aux pixel index (permuted rows: the pixel itself, taken from the tensor start)
+            if (e_dense) { pixrel = e_rowtab[ok ? m : mb]; off = (int64_t)pixrel * e_sx; }
+            else {
+                const int mm = ok ? m : mb;
+                const int b = mm / HoWo, rr_ = mm - b * HoWo;
+                const int oy = rr_ / e_Wo, ox = rr_ - oy * e_Wo;
+                const int Y = oy * e_osy + ooy_ph, X = ox * e_osx + oox_ph;
+                off = e_ps ? (int64_t)b * e_sb + (int64_t)(2 * Y) * e_sy + (int64_t)(2 * X) * e_sx
+                                      : (int64_t)b * e_sb + (int64_t)Y * e_sy + (int64_t)X * e_sx;
+                // the tile's first row is a live row (mb < M) and the rows of a tile ascend: offsets are taken relative to it
+                off0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)off >> 32)) << 32) |
+                                 (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)off));
+            }
+            const uint32_t rel = ok ? (uint32_t)((off - off0) * 4) : 0x80000000u;      // bytes; >= num_records: the store is dropped
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the previous tile's reads of the table are complete
+            if (lane < 32) { rowtab_lds[lane] = rel; rowtab_lds[32 + lane] = (uint32_t)pixrel; }
+        }
+        // rows beyond M: DIRECT -- the descriptor ends behind the tile's last live row (a lane's own offset n*4 is smaller than a pixel
+        // stride, and the range check looks at the vector offset, which holds the row part); table form -- their entry is out of range
+        const int rows_live = e_M - mb < 32 ? e_M - mb : 32;
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(outp + off0, 0, DIRECT ? (int)((int64_t)rows_live * e_sx * 4) : 0x7fffffff, 0x00020000);
+        // aux tiles: four LDS-DMA loads per tile and tensor into the idle stage buffers -- one memory latency per wave instead of 16
+        // dependent global loads, no extra VGPRs
+        if (U0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // row table written; the previous tile's reads of the aux region complete
+            // the four pieces' pixel indices BEFORE the first DMA goes out: behind a plain LDS load hipcc drains vmcnt whenever an LDS-DMA
+            // is in flight
+            int prow4[4];
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+            for (int k = 0; k < 4; ++k) {
+                const int row = (k * 64 + lane) >> 3;
+                prow4[k] = DIRECT ? row : (int)rowtab_lds[32 + row];
+            }
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            if (j >= nlive) continue;
-            const int mb = m0 + wm * 32 * TM + i * 32, nb = n0 + (wn * TN + j) * 32;
-            if (mb >= p.M) continue;
-            const int n = nb + l31;
-            const float bv = (bias && n < p.Cout) ? bias[n] : 0.0f;
-            if (p.dense_out) {
-                // PERM (compile-time in each copy): permuted rows -- the output / aux pixel of tile row `row` is rowtab[mb + row].  The
-                // plain copy is the code as it was: a run-time select in the store loop cost the aux epilogues 5-15 %.
-                auto dense_tile = [&](auto perm_tag) {
-                    constexpr bool PERM = decltype(perm_tag)::value;
-                    // permuted rows: the 32 pixel indices of this tile's rows go through LDS (the run table's space: the K loop is over).
-                    // Read from global memory inside the store loop they put a `vmcnt(0)` -- which on gfx9 also counts the stores
-                    // in flight -- in front of every store: sixteen store round trips per tile, one after the other.
-                    int* prow_lds = reinterpret_cast<int*>(runs) + wave * 32;
-                    if (PERM) {
-                        if (lane < 32) prow_lds[lane] = mb + lane < p.M ? p.rowtab[mb + lane] : 0;
-                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    }
-                    if (u0) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // the previous tile's reads of this region are complete
+            for (int a = 0; a < 2; ++a) {
+                if (a == 1 && !U1) break;
+                const int ld = a == 0 ? ld0_v : ld1_v;
+                const float* src = (a == 0 ? aux0_p : aux1_p) + (DIRECT ? (int64_t)mb * ld : (int64_t)0) + nb;
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            if (a == 1 && !u1) break;
-                            const int ld = a == 0 ? p.ld0 : p.ld1;
-                            const float* src = (a == 0 ? p.aux0 : p.aux1) + (PERM ? (int64_t)0 : (int64_t)mb * ld) + nb;
-                            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, 0x7fffffff, 0x00020000);
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
-                                const bool ok = mb + row < p.M && nb + 4 * cq < p.Cout;
-                                int prow = row;
-                                if (PERM) prow = prow_lds[row];
-                                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
-                                                                         ok ? (prow * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
-                            }
-                        }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    }
-                    if (n < p.Cout) {
-                        for (int r = 0; r < 16; ++r) {
-                            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                            const int m = mb + row;
-                            if (m >= p.M) continue;
-                            float v = acc[i][j][r];
-                            if (bias) v = v + bv;
-                            const float a0 = u0 ? tile[row * 32 + l31] : 0.0f, a1 = u1 ? tile[1024 + row * 32 + l31] : 0.0f;
-                            int64_t opix = m;
-                            if (PERM) opix = prow_lds[row];
-                            outp[opix * p.out_sx + (int64_t)n * p.out_sc] = epilogue_apply(p.epi, v, a0, a1);
-                        }
-                    }
-                };
-                if (p.rowperm) dense_tile(std::true_type{}); else dense_tile(std::false_type{});
-            } else {
-                for (int r = 0; r < 16; ++r) {
-                    const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int m = mb + row;
-                    if (m >= p.M || n >= p.Cout) continue;
-                    const int b = m / HoWo, rr = m - b * HoWo;
-                    const int oy = rr / p.Wo, ox = rr - oy * p.Wo;
-                    const int Y = oy * p.osy + p.ooy[phase], X = ox * p.osx + p.oox[phase];
-                    float v = acc[i][j][r];
-                    if (bias) v = v + bv;
-                    int nn = n, YY = Y, XX = X;
-                    if (p.pixel_shuffle) { nn = n >> 2; YY = 2 * Y + ((n >> 1) & 1); XX = 2 * X + (n & 1); }
-                    const int64_t pix = ((int64_t)b * p.outH + YY) * p.outW + XX;
-                    v = epilogue_value(p, v, pix, nn);
-                    outp[(int64_t)b * p.out_sb + (int64_t)YY * p.out_sy + (int64_t)XX * p.out_sx + (int64_t)nn * p.out_sc] = v;
+                for (int k = 0; k < 4; ++k) {
+                    const int pc = k * 64 + lane, row = pc >> 3, cq = pc & 7;
+                    const bool okp = mb + row < e_M && nb + 4 * cq < e_Cout;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(tile + a * 1024 + k * 256), 16,
+                                                             okp ? (prow4[k] * ld + 4 * cq) * 4 : OOB, 0, 0, 0);
                 }
             }
         }
+        uint32_t lane_off;                                            // bytes: this lane's part of a store's offset
+        if (DIRECT) lane_off = (uint32_t)((4 * half * (int)e_sx + n) * 4);
+        else if (e_ps) lane_off = (uint32_t)((((n >> 1) & 1) * (int)e_sy + (n & 1) * (int)e_sx + (n >> 2)) * 4);
+        else lane_off = (uint32_t)n * 4u;
+        const uint32_t sx4 = (uint32_t)e_sx * 4u;
+        // this lane's rows 8q + 4*half + {0..3} are accumulator registers 4q + {0..3}; their table entries are one ds_read_b128
+        u32x4 rq = {0u, 0u, 0u, 0u};
+        auto read_rows = [&](int q) __attribute__((always_inline)) {
+            if (DIRECT) return;
+            u32x4 t;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(t) : "v"(rowtab_lds_addr + (uint32_t)half * 16u + (uint32_t)q * 32u) : "memory");
+            rq = t;
+        };
+        read_rows(0);
+        // aux tiles landed, first row offsets here (tied to the wait: nothing that uses them may be scheduled above it)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rq) :: "memory");
+        if (n < e_Cout) {
+            const bool hb = bias != nullptr;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a0v[4], a1v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = e + 8 * q + 4 * half;
+                    a0v[e] = U0 ? tile[row * 32 + l31] : 0.0f;
+                    a1v[e] = U1 ? tile[1024 + row * 32 + l31] : 0.0f;
+                }
+                const u32x4 rcur = rq;
+                if (q < 3) read_rows(q + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float v = acc[i][j][4 * q + e];
+                    if (hb) v = v + bv;
+                    const float o = epilogue_apply(EPI, v, a0v[e], a1v[e]);
+                    uint32_t ro;
+                    if (DIRECT) ro = (uint32_t)(8 * q + e) * sx4;
+                    else ro = e == 0 ? rcur.x : (e == 1 ? rcur.y : (e == 2 ? rcur.z : rcur.w));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, (int)(ro + lane_off), 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);                   // one element at a time: interleaved, the 16 GELUs cost 20 VGPRs (one wave per SIMD less)
+                }
+                if (!DIRECT && q < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq) :: "memory");
+            }
+        }
+    };
+    auto finish = [&](auto epi_tag, auto direct_tag) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j >= nlive) continue;
+                if (m0 + wm * 32 * TM + i * 32 >= e_M) continue;
+                // (compile-time tile indices: the accumulators are addressed directly)
+                if (i == 0 && j == 0) fast_tile(epi_tag, direct_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                if constexpr (TN > 1) { if (i == 0 && j == 1) fast_tile(epi_tag, direct_tag, std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); }
+                if constexpr (TM > 1) { if (i == 1 && j == 0) fast_tile(epi_tag, direct_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); }
+                if constexpr (TM > 1 && TN > 1) { if (i == 1 && j == 1) fast_tile(epi_tag, direct_tag, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); }
+            }
+    };
+    static_assert(TM <= 2 && TN <= 2, "tile indices of the epilogue dispatch");
+    if (!fast) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (j >= nlive) continue;
+                if (m0 + wm * 32 * TM + i * 32 >= e_M) continue;
+                if (i == 0 && j == 0) slow_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+                if constexpr (TN > 1) { if (i == 0 && j == 1) slow_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); }
+                if constexpr (TM > 1) { if (i == 1 && j == 0) slow_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); }
+                if constexpr (TM > 1 && TN > 1) { if (i == 1 && j == 1) slow_tile(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); }
+            }
+    } else if constexpr (TM * TN == 1) {
+        const bool direct = e_dense && !e_perm && (int64_t)32 * e_sx * 4 < ((int64_t)1 << 31);
+        switch (epi_v) {
+#define PC_EPI_CASE(E) case E: if (direct) finish(std::integral_constant<int, E>{}, std::true_type{}); else finish(std::integral_constant<int, E>{}, std::false_type{}); break;
+        PC_EPI_CASE(PC_EPI_GELU) PC_EPI_CASE(PC_EPI_RES_GELU) PC_EPI_CASE(PC_EPI_RES) PC_EPI_CASE(PC_EPI_GATE) PC_EPI_CASE(PC_EPI_GDN)
+        PC_EPI_CASE(PC_EPI_IGDN) PC_EPI_CASE(PC_EPI_CLAMP01) PC_EPI_CASE(PC_EPI_LRP) PC_EPI_CASE(PC_EPI_LRP_ADD) PC_EPI_CASE(PC_EPI_LEAKY)
+        PC_EPI_CASE(PC_EPI_LEAKY_RES)
+#undef PC_EPI_CASE
+        default: if (direct) finish(std::integral_constant<int, PC_EPI_NONE>{}, std::true_type{}); else finish(std::integral_constant<int, PC_EPI_NONE>{}, std::false_type{}); break;
+        }
+    }
     stamp_out();
 #endif
 }
@@ -1409,36 +1187,6 @@ void conv_rowtab_unpin(const pc_conv_params& p)
     rc->unpin(p.rowtab);
 }
 
-template <int BK, int S, int WM, int WN, bool SQ = false>
-hipError_t launch_dma(const pc_conv_params& p, hipStream_t stream)
-{
-    constexpr int BM = 32 * WM, BN = 32 * WN;
-    int tmax = 0;
-    for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
-    const size_t lds = (size_t)S * (BM + BN) * (BK / 4) * 16 + (size_t)tmax * p.nseg * sizeof(pc_run);
-    const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
-    dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);       // 1-D: the kernel maps workgroup id -> (XCD band, M tile, N tile, phase/group)
-    const bool stamps = (p.dbg & 64) != 0;
-    auto kern = stamps ? conv_igemm_dma_kernel<BK, S, WM, WN, true, SQ> : conv_igemm_dma_kernel<BK, S, WM, WN, false, SQ>;
-    static std::atomic<uint32_t> attr_set[2];             // per instantiation, bit per device: more than 64 KB of dynamic LDS allowed
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (lds > 48 * 1024 && !(attr_set[stamps].load(std::memory_order_acquire) & (1u << (dev & 31)))) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256) != hipSuccess)
-            return hipGetLastError();
-        attr_set[stamps].fetch_or(1u << (dev & 31), std::memory_order_release);
-    }
-    static std::atomic<int> printed{0};
-    if ((p.dbg & 256) && printed.fetch_add(1) == 0) {
-        int nb = -1;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kern, 128 * WM * WN, lds);
-        fprintf(stderr, "[pc_conv] dma<%d,%d,%d,%d> grid %u x %u x %u, lds %zu B, max active blocks per CU %d\n", BK, S, WM, WN, grid.x, grid.y,
-                grid.z, lds, nb);
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(128 * WM * WN), lds, stream, p);
-    return hipGetLastError();
-}
-
 template <int BK, int S, int TM, int TN, bool SQ = false, int DBG = 0>
 hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
 {
@@ -1449,7 +1197,8 @@ hipError_t launch_uni(const pc_conv_params& p, hipStream_t stream)
     const bool u0 = u1 || p.epi == PC_EPI_RES_GELU || p.epi == PC_EPI_RES || p.epi == PC_EPI_GDN || p.epi == PC_EPI_IGDN || p.epi == PC_EPI_LRP ||
                     p.epi == PC_EPI_LEAKY_RES;                                                 // epilogue_uses_aux0
     const size_t stage_bytes = (size_t)S * (BM + BN) * (BK / 4) * 16, epi_bytes = !p.dense_out ? 0 : (u1 ? 32768 : (u0 ? 16384 : 0));
-    const size_t lds = std::max(stage_bytes, epi_bytes) + (size_t)tmax * p.nseg * 2 * sizeof(pc_run);
+    // stages (or the epilogue's aux tiles, whichever is larger), then the run table of the K loop / the epilogue's row tables (256 B per wave)
+    const size_t lds = std::max(stage_bytes, epi_bytes) + std::max((size_t)tmax * p.nseg * 2 * sizeof(pc_run), (size_t)1024);
     const int MT = (p.M + BM - 1) / BM, NT = (p.Cout + BN - 1) / BN, NZ = p.ngroup == 2 ? 2 : p.nphase;
     dim3 grid(8 * ((MT + 7) / 8) * NT * NZ, 1, 1);
     auto kern = conv_igemm_uni_kernel<BK, S, TM, TN, SQ, DBG>;
@@ -1519,6 +1268,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         int maxld = 0;
         for (int sg = 0; sg < p.nseg; ++sg) maxld = std::max(maxld, p.seg[sg].ld);
         maxld = std::max(maxld, std::max(p.ld0, p.ld1));
+        maxld = std::max(maxld, (int)std::min<int64_t>(p.out_sx, 0x7fffffff));   // the epilogue's output offsets of permuted rows are 32-bit too
         const bool dense = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho && p.outW == p.Wo &&
                            !p.pixel_shuffle && p.out_sy == (int64_t)p.outW * p.out_sx && p.out_sb == (int64_t)p.outH * p.out_sy;
         p.rowperm = (perm_on && uni_on && !no_tab && p.wlayout == 1 && !p.square && !p.smallc && tmax > 1 && tmax <= 25 && p.nphase == 1 && p.stride == 1 &&
@@ -1590,6 +1340,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
             const int ab = (p.dbg & 64) ? 0 : (p.dbg & 15);                   // ablation builds of the 64x64 three-stage instantiation
             if (p.square) e = launch_uni<32, 2, 1, 1, true>(p, stream);
+#ifdef PC_CONV_TUNING   // ablation builds of the 64x64 three-stage instantiation (make FLAGS+=-DPC_CONV_TUNING): no MFMAs / no DMA issue / zero-fill DMAs / no operand reads ...
             else if (ab == 1) e = launch_uni<32, 3, 1, 1, false, 1>(p, stream);
             else if (ab == 2) e = launch_uni<32, 3, 1, 1, false, 2>(p, stream);
             else if (ab == 4) e = launch_uni<32, 3, 1, 1, false, 4>(p, stream);
@@ -1598,25 +1349,21 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             else if (ab == 3) e = launch_uni<32, 3, 1, 1, false, 3>(p, stream);
             else if (ab == 0 && (p.dbg & 16) && !(p.dbg & 64)) e = launch_uni<32, 3, 1, 1, false, 16>(p, stream);
             else if ((p.dbg & 64) && (p.dbg & 8)) e = launch_uni<32, 3, 1, 1, false, 74>(p, stream);
+#endif
+            else if ((p.dbg & 64) && bk == 16) e = launch_uni<16, 3, 1, 1, false, 64>(p, stream);   // timeline of the default large-grid instantiation (PC_CONV_BK=16)
             else if (p.dbg & 64) e = launch_uni<32, 3, 1, 1, false, 64>(p, stream);
             else if (bk == 16 && tm == 1 && tn == 1 && s_env == 2) e = launch_uni<16, 2, 1, 1>(p, stream);
             else if (bk == 16 && tm == 1 && tn == 1 && s_env == 3) e = launch_uni<16, 3, 1, 1>(p, stream);
-            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 5) e = launch_uni<16, 5, 1, 1>(p, stream);
-            else if (bk == 16 && tm == 1 && tn == 1 && s_env == 6) e = launch_uni<16, 6, 1, 1>(p, stream);
             else if (bk == 16 && tm == 1 && tn == 1) e = launch_uni<16, 4, 1, 1>(p, stream);
             else if (policy == 1 && !s_env && !tm_env && !tn_env) e = launch_uni<16, 3, 1, 1>(p, stream);
             else if (policy == 2 && !s_env && !tm_env && !tn_env && tm == 1) e = launch_uni<16, 3, 1, 1>(p, stream);
             else if (policy == 3 && !s_env && !tm_env && !tn_env && nb64 > small_thr) e = launch_uni<16, 3, 1, 1>(p, stream);
             else if (policy == 3 && !s_env && !tm_env && !tn_env) e = chunks <= 8 ? launch_uni<32, 2, 1, 1>(p, stream) : launch_uni<32, 3, 1, 1>(p, stream);
 #define PC_UNI_CASE(S_, TM_, TN_) else if (Su == S_ && tm == TM_ && tn == TN_) e = launch_uni<32, S_, TM_, TN_>(p, stream);
-            PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(3, 1, 2) PC_UNI_CASE(2, 1, 2)
-            PC_UNI_CASE(3, 2, 2) PC_UNI_CASE(2, 2, 2) PC_UNI_CASE(4, 1, 1)
+            PC_UNI_CASE(3, 1, 1) PC_UNI_CASE(2, 1, 1) PC_UNI_CASE(3, 2, 1) PC_UNI_CASE(2, 2, 1) PC_UNI_CASE(2, 1, 2)
+            PC_UNI_CASE(2, 2, 2)
 #undef PC_UNI_CASE
         }
-        else if (p.square) e = launch_dma<32, 2, 2, 2, true>(p, stream);        // GDN / IGDN: K = C <= 320
-#define PC_DMA_CASE(BK_, S_) else if (bk == BK_ && S == S_) e = launch_dma<BK_, S_, 2, 2>(p, stream);
-        PC_DMA_CASE(32, 3) PC_DMA_CASE(32, 2) PC_DMA_CASE(32, 4) PC_DMA_CASE(64, 2) PC_DMA_CASE(64, 3)
-#undef PC_DMA_CASE
         if (e == hipErrorInvalidValue) return PC_ERR_ARG;
     } else {
         if (p.ngroup == 2) return PC_ERR_ARG;

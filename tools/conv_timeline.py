@@ -29,7 +29,7 @@ def main():
         out = torch.empty((B, Ho, Wo, co), device="cuda")
         P = lambda t: C.c_void_p(t.data_ptr())
         for _ in range(3):
-            check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), 0, co, k, s, 0, 0, P(out), None))
+            check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), 0, co, k, s, int(os.environ.get('PC_TUNE_ACT', '0')), 0, P(out), None))
         torch.cuda.synchronize()
         st = np.zeros((8192, 16), np.uint64)
         check(L.pc_debug_read_stamps(st.ctypes.data_as(C.c_void_p), 8192))
@@ -72,7 +72,7 @@ def main():
         for r in sorted(order_dur):
             a = np.array(order_dur[r])
             print(f"   block #{r} on its CU: prologue {a[:,0].mean():6.1f} us  K loop {a[:,1].mean():7.1f} us (min {a[:,1].min():.1f} max {a[:,1].max():.1f})  epilogue {a[:,2].mean():6.1f} us  [{len(a)} waves]")
-        for c in list(per_cu)[:2]:
+        for c in list(per_cu)[:int(os.environ.get('PC_TIMELINE_CUS', '2'))]:
             m = cuid == c
             print(f"   CU {c}:")
             for i in sorted(np.nonzero(m)[0], key=lambda i: (T[i, 0], blk[i], simd[i])):

@@ -80,7 +80,7 @@ def main():
         P = lambda t: C.c_void_p(t.data_ptr())
         for cfg in cfgs:
             def run():
-                check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), kind, co, k, s, 0, cfg, P(out), None))
+                check(L.pc_conv2d_nhwc(P(x), B, H, W, ci, P(w), P(b), kind, co, k, s, int(os.environ.get('PC_TUNE_ACT', '0')), cfg, P(out), None))
             try:
                 run()
             except Exception as e:

@@ -14,12 +14,10 @@ run PC_CONV_POLICY=0
 run PC_CONV_POLICY=1
 run PC_CONV_POLICY=2
 run PC_CONV_POLICY=3 PC_CONV_SMALL_THR=100000
-run PC_CONV_KERN=0
 run PC_CONV_BK=16 PC_CONV_S=2 PC_CONV_TM_THR=100000000
 run PC_CONV_BK=16 PC_CONV_S=4 PC_CONV_TM_THR=100000000
-run PC_CONV_BK=16 PC_CONV_S=6 PC_CONV_TM_THR=100000000
 run PC_CONV_S=2
-run PC_CONV_S=4 PC_CONV_TM_THR=100000000
+run PC_CONV_S=3 PC_CONV_TM=2
 run PC_CONV_TM=2 PC_CONV_TN=2
 run PC_CONV_ROWPERM=0
 run PC_CONV_ROWPERM_MIN=0

@@ -6,16 +6,13 @@ set -o pipefail
 TAG=${1:-r02_x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; P=$O/profiles_$TAG; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
-rm -rf $O/prof_stats_default $O/prof_stats_1lane $O/prof_stats_1lane_r01kernel $O/pmc_FETCH $O/pmc_WRITE $O/prof_stage $O/pmc_clk_serial
+rm -rf $O/prof_stats_default $O/prof_stats_1lane $O/pmc_FETCH $O/pmc_WRITE $O/prof_stage $O/pmc_clk_serial
 # serial form: one lane, one stream, no pipelining inside the codec and no encoder / decoder overlap -- a launch's duration is its own
 SER="PC_LANES=1 PC_DUAL_STREAM=0 PC_PIPELINE=0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_default -o run -- python3 $R/bench.py --steps 10 --warmup 2 --lean > $O/prof_stats_default.log 2>&1 || exit 1
 echo "default stats done"
 env $SER timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 > $O/prof_stats_1lane.log 2>&1 || exit 1
 echo "1lane stats done"
-# the round-1 kernel and tile choice on the same box, same serial form (cross-box comparisons carry +-5 %)
-env $SER PC_CONV_KERN=0 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane_r01kernel -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 > $O/prof_stats_1lane_r01kernel.log 2>&1 || exit 1
-echo "1lane r01-kernel stats done"
 env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_FETCH -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_FETCH.log 2>&1 || exit 1
 env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_WRITE -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_WRITE.log 2>&1 || exit 1
 env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_clk_serial -o run -- python3 $R/bench.py --steps 2 --warmup 1 --lean --overlap 0 > $O/pmc_clk_serial.log 2>&1 || exit 1
@@ -27,9 +24,7 @@ PC_PROFILE_CSV=$P/${TAG}_conv_launches_bench_b32.csv timeout -k 10 300 python3 b
 grep -h '^{' $O/prof_launches.log | tail -1 > $P/${TAG}_bench_default_no_profiler.json
 python3 tools/rocpd_stats.py $O/prof_stats_default > $P/${TAG}_kernel_stats_bench_b32_default.csv
 python3 tools/rocpd_stats.py $O/prof_stats_1lane > $P/${TAG}_kernel_stats_bench_b32_1lane.csv
-python3 tools/rocpd_stats.py $O/prof_stats_1lane_r01kernel > $P/${TAG}_kernel_stats_bench_b32_1lane_r01kernel_same_box.csv
 python3 tools/pmc_clock.py $O/pmc_clk_serial > $P/${TAG}_clock_mfma_util_serial.json
-grep -h '^{' $O/prof_stats_1lane_r01kernel.log | tail -1 > $P/${TAG}_bench_under_rocprof_1lane_r01kernel_same_box.json
 grep -h '^{' $O/prof_stats_default.log | tail -1 > $P/${TAG}_bench_under_rocprof_default.json
 python3 tools/pmc_traffic.py $O/pmc_FETCH $O/pmc_WRITE > $P/${TAG}_hbm_traffic.json
 python3 tools/stage_rocprof.py $O/prof_stage 256 > $P/${TAG}_stage_kernels_rocprof.json
