@@ -254,6 +254,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
     }
 
     // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    // Dense NHWC output on the GEMM's own pixel grid without aux tensors (the 3-channel input layer: 402 MB of output at Config 2): the
+    // output pixel of a row is the row itself -- no divisions, the 16 rows unrolled, buffer stores relative to the tile's first row with
+    // the rows beyond M dropped by the range check (same form as conv_igemm_uni_kernel's direct epilogue).
+    if (p.dense_out && p.out_sc == 1 && !epilogue_uses_aux0(p.epi) && (int64_t)32 * p.out_sx * 4 < ((int64_t)1 << 31)) {
+        const int epi_v = p.epi;
+        const uint32_t sx4 = (uint32_t)p.out_sx * 4u;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int mb = m0 + wm * (TM * 32) + i * 32;
+            if (mb >= p.M) continue;
+            const int rows_live = p.M - mb < 32 ? p.M - mb : 32;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.out + (int64_t)mb * p.out_sx, 0, (int)((int64_t)rows_live * p.out_sx * 4), 0x00020000);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (TN * 32) + j * 32 + l31;
+                if (n >= p.Cout) continue;
+                const float bv = p.bias ? p.bias[n] : 0.0f;
+                const bool hb = p.bias != nullptr;
+                const uint32_t lane_off = (uint32_t)((4 * half * (int)p.out_sx + n) * 4);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (hb) v = v + bv;
+                    v = epilogue_apply(epi_v, v, 0.0f, 0.0f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (int)((uint32_t)((r & 3) + 8 * (r >> 2)) * sx4 + lane_off), 0, 0);
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -334,8 +364,10 @@ struct pc_run { const float* a_base; const float* w_base; int ld, nch, tap, pad;
 //            MFMAs of chunk c, with the NI pieces of chunk c+S-1 (into the stage chunk c-1 occupied) between them
 // ------------------------------------------------------------------------------------------
 // DBG (tuning builds only, PC_CONV_DBG): 1 no MFMAs, 2 no DMA issue, 4 every DMA piece out of range (zero fill, no L2 traffic), 8 no operand reads
+// (register budget: the K-chunk-16 instantiation serves the grids with several workgroups per CU and is held to six waves per SIMD --
+// the unrolled epilogue alone would take 96 registers, five waves; K-chunk 32 serves the one-workgroup-per-CU grids)
 template <int BK, int S, int TM, int TN, bool SQ, int DBG = 0>
-__global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_params p)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 1 ? (BK == 16 ? 6 : 5) : 1))) void conv_igemm_uni_kernel(const pc_conv_params p)
 {
     constexpr int BM = 64 * TM, BN = 64 * TN, KQ = BK / 4;
     constexpr int NTH = 256;
@@ -787,6 +819,7 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
     //    row: 32-bit offsets, rows beyond M dropped by the hardware's range check.
     // Same arithmetic on the same values in the same order: the bits do not move.
     if (nlive == 0) { stamp_out(); return; }
+    // (raising the wave's priority for the epilogue -- VALU work beside the other workgroups' MFMA issue -- changed nothing: profiles/r03_g_*)
     const bool u0 = epilogue_uses_aux0(p.epi), u1 = epilogue_uses_aux1(p.epi);
     // LDS: the stages are free now.  Aux tiles of the tile being finished, 4 KB each: aux0 alone -> 4 KB per wave, aux0 + aux1 -> 8 KB per
     // wave at the start of the allocation; behind them (and behind the stages, whichever is larger: launch_uni sizes it) 64 words per
@@ -949,6 +982,36 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             }
         }
     };
+    // NCHW output with PixelShuffle(2) folded into the store (the 192 -> 3 output layer in 12-column sub-pixel form: x_hat [B][3][2H][2W]).
+    // With lane = column every store instruction wrote 12 scattered dwords -- a 64-byte write request per 4-byte element, 403 MB of
+    // WRITE_SIZE for the 25 MB tensor (profiles/r02_z_hbm_traffic.json).  A tile's 32 rows are 32 consecutive x of one image row
+    // (Wo % 32 == 0), so for a fixed (colour, row parity) the tile owns 64 CONSECUTIVE output floats: the tile goes through LDS
+    // ([row][col], 33-word pitch) and each (colour, parity) pair leaves as one 256-byte store, lane = output x.
+    auto nchw_ps_tile = [&](auto i_tag, auto j_tag) __attribute__((always_inline)) {
+        constexpr int i = decltype(i_tag)::value, j = decltype(j_tag)::value;
+        const int mb = m0 + wm * 32 * TM + i * 32, nb = n0 + (wn * TN + j) * 32;
+        const int n = nb + l31;
+        const float bv = (bias && n < e_Cout) ? bias[n] : 0.0f;
+        float* t = reinterpret_cast<float*>(smem) + wave * 1056;      // 32 x 33 floats per wave (the stages are free)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // the previous tile's reads are complete
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[i][j][r];
+            if (bias) v = v + bv;
+            t[row * 33 + l31] = epilogue_apply(epi_v, v, 0.0f, 0.0f);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // a wave's LDS operations execute in order; the tile is wave-private
+        const int b = mb / HoWo, rr_ = mb - b * HoWo;
+        const int oy = rr_ / e_Wo, ox0 = rr_ - oy * e_Wo;             // the tile: pixels (oy, ox0 .. ox0 + 31) of image b
+        const int Y = oy * e_osy + ooy_ph, X0 = ox0 * e_osx + oox_ph;
+        const int ncp = (e_Cout - nb < 32 ? e_Cout - nb : 32) >> 1;   // (colour, row parity) pairs among this tile's columns
+        for (int cp = 0; cp < ncp; ++cp) {
+            const int nn = nb + 2 * cp;                               // column of px = 0
+            const float v = t[(lane >> 1) * 33 + 2 * cp + (lane & 1)];
+            outp[(int64_t)b * e_sb + (int64_t)(nn >> 2) * e_sc + (int64_t)(2 * Y + ((nn >> 1) & 1)) * e_sy + (int64_t)(2 * X0 + lane) * e_sx] = v;
+        }
+    };
     auto finish = [&](auto epi_tag, auto direct_tag) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -964,7 +1027,11 @@ __global__ __launch_bounds__(256) void conv_igemm_uni_kernel(const pc_conv_param
             }
     };
     static_assert(TM <= 2 && TN <= 2, "tile indices of the epilogue dispatch");
-    if (!fast) {
+    const bool nchw_ps = TM * TN == 1 && e_ps && !e_dense && !u0 && e_sx == 1 && e_osx == 1 && e_osy == 1 && e_Wo % 32 == 0 && e_M % 32 == 0 && (e_Cout & 3) == 0 &&
+                         (size_t)S * STAGE * 16 >= (size_t)4 * 1056 * 4;
+    if (nchw_ps) {
+        if constexpr (TM * TN == 1) { if (m0 + wm * 32 < e_M) nchw_ps_tile(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); }
+    } else if (!fast) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
