@@ -405,9 +405,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
     const int m_local = slot / (NT * NZ), nz = slot - m_local * (NT * NZ);
     // permuted rows: the cheap border tiles are the last tiles of the launch -- deal the tiles round-robin over the XCDs so that every
     // XCD ends on its share of them (contiguous bands would leave them all to the last XCD and the launch would end no earlier)
-    const int m_tile = p.rowperm ? m_local * 8 + xcd : xcd * mpx + m_local;
+    int m_tile = p.rowperm ? m_local * 8 + xcd : xcd * mpx + m_local;
+    int zsel = nz / NT, n_tile = nz - zsel * NT;
+    if (p.group_xcd) {
+        // Grouped launch (cc_mean || cc_scale): with both groups on every XCD an L2 streams 2 x NT weight slabs -- 9.4 MB at N = 224 against
+        // 4 MB of L2 -- and the heads fetched 12x their operands (profiles/r03_m_traffic_by_shape.json; 4.4x ungrouped).  Here XCDs 0-3
+        // run group 0 and XCDs 4-7 group 1: the same workgroups, each L2 sees one group's slabs.
+        const int x4 = xcd & 3, per = 2 * mpx;                       // M tiles this XCD may take (>= MT / 4)
+        const int ml = slot / NT;
+        zsel = xcd >> 2; n_tile = slot - ml * NT;
+        m_tile = p.rowperm ? ml * 4 + x4 : x4 * per + ml;
+    }
     if (m_tile >= MT) return;
-    const int zsel = nz / NT, n_tile = nz - zsel * NT;
     int phase = zsel;
     const float* seg0_ptr = p.seg[0].ptr;
     const float* wbase = p.w;
@@ -1345,6 +1354,8 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         p.rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
         if (!p.rowtab) p.rowperm = 0;
     }
+    static const bool group_xcd_on = [] { const char* v = std::getenv("PC_CONV_GROUP_XCD"); return !v || std::atoi(v) != 0; }();
+    p.group_xcd = (group_xcd_on && p.ngroup == 2 && p.wlayout == 1) ? 1 : 0;
     p.ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
                                                 p.Ho == p.H && p.Wo == p.W;
     p.dense_out = p.nphase == 1 && p.osy == 1 && p.osx == 1 && p.ooy[0] == 0 && p.oox[0] == 0 && p.outH == p.Ho &&

@@ -75,6 +75,7 @@ struct pc_conv_params {
     int dense_out;                           // set by pc_conv_launch: output pixel index == GEMM row (plain NHWC-strided store)
     int rowperm;                             // set by pc_conv_launch: the row table is a PERMUTATION of the pixels (rows grouped by tap-validity
                                              // pattern, so that a tile's padding taps can be skipped as whole runs); output pixel of row m = rowtab[m]
+    int group_xcd;                           // set by pc_conv_launch (grouped launches): XCDs 0-3 run group 0, XCDs 4-7 group 1 -- each L2 streams one group's weight slabs
     int dbg;                                 // tuning only (PC_CONV_DBG bits): 1 skip MFMAs, 2 skip DMA issue, 4 DMAs read the zero page, 64 stamps, 256 print occupancy
 };
 

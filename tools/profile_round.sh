@@ -32,7 +32,7 @@ python3 tools/pmc_clock.py $O/pmc_clk_serial > $P/${TAG}_clock_mfma_util_serial.
 grep -h '^{' $O/prof_stats_default.log | tail -1 > $P/${TAG}_bench_under_rocprof_default.json
 python3 tools/overlap_mfma.py $O/prof_stats_default $P/${TAG}_bench_under_rocprof_default.json > $P/${TAG}_overlap_schedule_mfma.json
 python3 tools/pmc_traffic.py $O/pmc_FETCH $O/pmc_WRITE > $P/${TAG}_hbm_traffic.json
-python3 tools/traffic_by_shape.py $O/pmc_FETCH $O/pmc_WRITE $O/pmc_FETCH_launches.csv > $P/${TAG}_traffic_by_shape.json
+python3 tools/traffic_by_shape.py $O/pmc_FETCH $O/pmc_WRITE $O/pmc_FETCH_launches.csv $P/${TAG}_conv_launches_bench_b32.csv > $P/${TAG}_traffic_by_shape.json
 python3 tools/stage_rocprof.py $O/prof_stage 256 $O/pmc_stage_FETCH $O/pmc_stage_WRITE > $P/${TAG}_stage_kernels_rocprof.json
 grep -h '^{' $O/prof_stats_1lane.log | tail -1 > $P/${TAG}_bench_under_rocprof_1lane.json
 grep -h '^{' $O/prof_stage.log > $P/${TAG}_stage_hbm_roofline_b256_events.jsonl

@@ -7,7 +7,10 @@ launch order -- the order of the CSV rows.  So the LAST len(csv) conv_igemm* dis
 by row.  FETCH_SIZE (KB) is doubled as MI355X_MICROARCH.md prescribes for gfx950; both counters sit on the L2's memory side, so
 Infinity-Cache hits are included: these are L2 misses, an upper bound of the HBM bytes.
 
-usage: python tools/traffic_by_shape.py <fetch_dir> <write_dir> <launch csv> > profiles/rNN_traffic_by_shape.json"""
+Times come from a launch table written WITHOUT a profiler attached (counter collection serialises the dispatches and stretches them): the
+optional fourth argument, same launch order.
+
+usage: python tools/traffic_by_shape.py <fetch_dir> <write_dir> <launch csv of the PMC pass> [<launch csv of an unprofiled run>] > profiles/rNN_traffic_by_shape.json"""
 import collections
 import csv
 import glob
@@ -30,6 +33,11 @@ def main():
     fd, wd, cf = sys.argv[1:4]
     launches = list(csv.DictReader(open(cf)))
     n = len(launches)
+    if len(sys.argv) > 4:                                      # durations of an unprofiled run of the same step
+        timed = list(csv.DictReader(open(sys.argv[4])))
+        assert len(timed) == n and all((a["M"], a["N"], a["K"], a["epi"]) == (b["M"], b["N"], b["K"], b["epi"]) for a, b in zip(launches, timed))
+        for a, b in zip(launches, timed):
+            a["us"] = b["us"]
     f, w = per_dispatch(fd, "FETCH_SIZE")[-n:], per_dispatch(wd, "WRITE_SIZE")[-n:]
     assert len(f) == n and len(w) == n, (len(f), len(w), n)
     agg = collections.OrderedDict()
@@ -46,7 +54,7 @@ def main():
         L = a["launches"]
         tr = (a["fetch_mb"] + a["write_mb"]) / L
         shapes.append({"M": M, "N": N, "K": K, "nphase": nph, "epi": epi, "gflop_per_launch": gf, "launches": L, "ms_per_step": round(a["us"] / 1e3, 3),
-                       "tflops": round(gf * L / a["us"] * 1e3 / 1e3, 1), "algorithmic_mb_per_launch": round(a["alg_mb"] / L, 2),
+                       "tflops": round(gf * L / a["us"] * 1e3, 1), "algorithmic_mb_per_launch": round(a["alg_mb"] / L, 2),
                        "fetch_mb_per_launch": round(a["fetch_mb"] / L, 2), "write_mb_per_launch": round(a["write_mb"] / L, 2),
                        "traffic_over_algorithmic": round(tr / (a["alg_mb"] / L), 2)})
     tot_alg = sum(a["alg_mb"] for a in agg.values())
