@@ -203,6 +203,10 @@ PC_API int pc_codec_set_cust_map(pc_codec* c, const float* cust_map);
  * pc_codec_finalize.  n_levels in 1..3 switches the refinement on for the following compress / decompress / forward calls (mu_std =
  * False, no checkpoint_rep), 0 switches it off (plain ChannelProgresssiveWACNN). */
 PC_API int pc_codec_set_rem(pc_codec* c, const double* check_levels, int n_levels);
+/* checkpoint_rep of PostRateProcessedNetwork.compress / decompress (models/CHProgREM.py:676,773 / :901,989): a device tensor NCHW
+ * [B][320][H/16][W/16] that replaces the decoded base slices as the x_base input of the LatentRateReduction nets in the NEXT compress /
+ * decompress call, then the pointer is cleared (what the escalation mode chains from check level to check level, :335-373).  NULL clears. */
+PC_API int pc_codec_set_rem_checkpoint(pc_codec* c, const float* checkpoint_rep);
 PC_API int pc_codec_num_slices(const pc_codec* c);
 /* string of y slice `slice` (0..n_slices-1) or of z (slice = -1) for image b */
 PC_API int pc_codec_get_string(const pc_codec* c, int slice, int b, const uint8_t** data, size_t* len);

@@ -382,8 +382,8 @@ class RefCodec:
 
     # ---- compress / decompress
     def refine_scale(self, i, quality, mask_pol, y_b_hat, mu_base, std_base, mu, scale):
-        """hook of the REM model (RemCodec below): the plain codec leaves the predicted scale alone"""
-        return scale
+        """hook of the REM model (RemCodec below): the plain codec leaves the predicted parameters alone.  Returns (mu, scale)."""
+        return mu, scale
 
     def compress(self, x, quality=0.0, mask_pol="point-based-std", taps=None, cust_map=None, force_enhanced=False):
         """ChannelProgresssiveWACNN.compress, models/CHProg_cnn.py:686-847.  force_enhanced (forward_single_quality only,
@@ -425,7 +425,7 @@ class RefCodec:
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
-            scale = self.refine_scale(i, quality, mask_pol, base[i], T[f"b{i}"]["mu"], T[f"b{i}"]["scale"], mu, scale)
+            mu, scale = self.refine_scale(i, quality, mask_pol, base[i], T[f"b{i}"]["mu"], T[f"b{i}"]["scale"], mu, scale)
             mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :819-824
             masks.append(mask)
             idx = self._indexes(scale * mask)                               # :828
@@ -530,7 +530,7 @@ class RefCodec:
             scale_support = torch.cat([ls[:, D0:]] + sup, 1)
             mu = self.stack5("cc_mean_transforms_prog", i, mean_support)
             scale = self.stack5("cc_scale_transforms_prog", i, scale_support)
-            scale = self.refine_scale(i, quality, mask_pol, base[i], mu_b[i], std_b[i], mu, scale)
+            mu, scale = self.refine_scale(i, quality, mask_pol, base[i], mu_b[i], std_b[i], mu, scale)
             mask = self._mask(scale, quality, mask_pol, cm[i] if cm is not None else None)   # :960-965
             idx = self._indexes(scale * mask)                               # :968
             sym = self._decode(y_strings[NS0 + i], idx, self.gc)
@@ -544,15 +544,22 @@ class RefCodec:
 
 # ----------------------------------------------------------------------------- REM (models/CHProgREM.py)
 class RemCodec(RefCodec):
-    """PostRateProcessedNetwork.compress / .decompress (models/CHProgREM.py:673-888, :896-1126) for mu_std=False, escalation=False,
-    checkpoint_rep=None, real_compress=True: the base codec's chain, with the predicted scale of every enhancement slice refined by a
-    LatentRateReduction CNN (:12-86) before the mask is taken -- apply_latent_enhancement (:375-428).  `post_sd`: the state dict of
-    `post_latent` ("<level>.<slice>.<subnet>.<block>.conv1.weight" ...)."""
+    """PostRateProcessedNetwork.compress / .decompress (models/CHProgREM.py:673-888, :896-1126), real_compress=True: the base codec's
+    chain, with the predicted scale -- and, with mu_std=True, the predicted mean too (:414-416) -- of every enhancement slice refined by a
+    LatentRateReduction CNN (:12-86) before the mask is taken: apply_latent_enhancement (:375-428).  `post_sd`: the state dict of
+    `post_latent` ("<level>.<slice>.<subnet>.<block>.conv1.weight" ...); the sub-net depth (dimension "big" / "middle") follows from
+    its keys.  `checkpoint_rep` (set_checkpoint_rep): a [B,320,h,w] representation that replaces the decoded base slices as the CNN's
+    x_base input (:773,989) -- what the escalation mode chains from level to level (:335-373)."""
 
-    def __init__(self, state_dict, post_sd, backend="torch", check_levels=(0.01, 0.25, 1.75), **kw):
+    def __init__(self, state_dict, post_sd, backend="torch", check_levels=(0.01, 0.25, 1.75), mu_std=False, **kw):
         super().__init__(state_dict, backend, **kw)
         self.post = {k: (v if isinstance(v, torch.Tensor) else torch.from_numpy(np.asarray(v))) for k, v in post_sd.items()}
         self.check_levels = list(check_levels)
+        self.mu_std = mu_std
+        self.checkpoint_rep = None
+
+    def set_checkpoint_rep(self, rep):
+        self.checkpoint_rep = rep
 
     def _rb(self, x, p):                                # ResidualBlock, models/utils.py:59-87
         w1, b1, w2, b2 = (self.post[f"{p}.{n}"] for n in ("conv1.weight", "conv1.bias", "conv2.weight", "conv2.bias"))
@@ -584,10 +591,10 @@ class RemCodec(RefCodec):
 
     def refine_scale(self, i, quality, mask_pol, y_b_hat, mu_base, std_base, mu, scale):
         """apply_latent_enhancement, :375-428 (attention mask = star - bar from the UNREFINED scale, rounded; nothing below the first
-        check level; the net of the quality's range), then LatentRateReduction.forward :74-86."""
+        check level; the net of the quality's range), then LatentRateReduction.forward :74-86.  Returns (mu, scale)."""
         c = self.check_levels
         if quality <= c[0]:
-            return scale
+            return mu, scale
         q_bar, _ = self.find_check_quality(quality)
         # the reference's call sites (:620,832,1060) do not forward mask_pol: the attention mask is always "point-based-std" (:385)
         att = torch.round(self._mask(scale, quality, "point-based-std") - self._mask(scale, q_bar, "point-based-std"))
@@ -598,11 +605,20 @@ class RemCodec(RefCodec):
         else:
             k = 0 if c[0] < quality <= c[1] else (1 if c[1] < quality <= c[2] else 2)
         p = f"{k}.{i}"
-        f_ent_prog = self._seq(scale, p + ".enc_enh_entropy_params")
+        if self.checkpoint_rep is not None:                                 # :773,989
+            y_b_hat = self.checkpoint_rep[:, 32 * i:32 * (i + 1)]
+        ident = torch.cat([mu, scale], 1) if self.mu_std else scale         # :789 mu_scale_enh
+        if self.mu_std:
+            att = torch.cat([att, att], 1)                                  # :397-398
+        f_ent_prog = self._seq(ident, p + ".enc_enh_entropy_params")
         f_latent = self._seq(y_b_hat, p + ".enc_base_rep")
         f_ent_base = self._seq(torch.cat([mu_base, std_base], 1), p + ".enc_base_entropy_params")
         ret = self._seq(torch.cat([f_latent, f_ent_base, f_ent_prog], 1), p + ".enc")
-        return ret * att + scale
+        out = ret * att + ident
+        if self.mu_std:
+            m2, s2 = out.chunk(2, 1)                                        # :414-416
+            return m2.contiguous(), s2.contiguous()
+        return mu, out
 
 
 # ----------------------------------------------------------------------------- harness (training/step.py:277-404)

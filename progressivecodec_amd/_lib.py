@@ -21,7 +21,7 @@ EXPORTS = [
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
     "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
     "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id", "pc_rans_decode_batch_u8", "pc_codec_set_rem",
-    "pc_codec_host_stats",
+    "pc_codec_host_stats", "pc_codec_set_rem_checkpoint",
 ]
 
 
@@ -85,6 +85,7 @@ def lib():
         L.pc_codec_decompress_levels.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]
         L.pc_codec_set_cust_map.argtypes = [vp, vp]
         L.pc_codec_set_rem.argtypes = [vp, vp, C.c_int]
+        L.pc_codec_set_rem_checkpoint.argtypes = [vp, vp]
         L.pc_codec_strings_size.argtypes = [vp, C.POINTER(sz), C.POINTER(C.c_int)]
         L.pc_codec_copy_strings.argtypes = [vp, vp, sz, vp, sz]
         L.pc_codec_decompress_packed.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_int, C.c_int, vp, vp]

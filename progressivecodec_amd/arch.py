@@ -199,22 +199,24 @@ def param_spec(cfg: CodecConfig = CodecConfig()) -> "OrderedDict[str, tuple]":
 REM_SUBNETS = ("enc_base_entropy_params", "enc_enh_entropy_params", "enc_base_rep", "enc")
 
 
-def rem_subnet_blocks(dimension="big", N=32):
-    """(in, out) channels of the ResidualBlocks of one LatentRateReduction (reference models/CHProgREM.py:12-72, mu_std=False)."""
+def rem_subnet_blocks(dimension="big", N=32, mu_std=False):
+    """(in, out) channels of the ResidualBlocks of one LatentRateReduction (reference models/CHProgREM.py:12-72).  mu_std=True: the
+    enhancement-parameter branch takes cat(mu, scale) (2N channels, :30,46) and the last block of `enc` returns 2N channels (:42,64)."""
     extra = [(N, N)] if dimension == "big" else []
+    e_in, e_out = (2 * N, 2 * N) if mu_std else (N, N)
     return {
         "enc_base_entropy_params": [(2 * N, N), (N, N)] + extra,
-        "enc_enh_entropy_params": [(N, N), (N, N)] + extra,
+        "enc_enh_entropy_params": [(e_in, N), (N, N)] + extra,
         "enc_base_rep": [(N, N), (N, N)] + extra,
-        "enc": [(3 * N, 2 * N), (2 * N, 2 * N)] + ([(2 * N, 2 * N)] if dimension == "big" else []) + [(2 * N, N)],
+        "enc": [(3 * N, 2 * N), (2 * N, 2 * N)] + ([(2 * N, 2 * N)] if dimension == "big" else []) + [(2 * N, e_out)],
     }
 
 
-def rem_param_spec(check_multiple=3, dimension="big", N=32) -> "OrderedDict[str, tuple]":
+def rem_param_spec(check_multiple=3, dimension="big", N=32, mu_std=False) -> "OrderedDict[str, tuple]":
     """State-dict layout of PostRateProcessedNetwork.post_latent (CHProgREM.py:227-234): [check level][slice] LatentRateReduction,
     each ResidualBlock = conv1 3x3, conv2 3x3 and, when in != out, a 1x1 skip (models/utils.py:59-87).  name -> (shape, dtype, kind)."""
     s = OrderedDict()
-    blocks = rem_subnet_blocks(dimension, N)
+    blocks = rem_subnet_blocks(dimension, N, mu_std)
     for k in range(check_multiple):
         for i in range(10):
             for sub in REM_SUBNETS:

@@ -94,6 +94,8 @@ struct pc_codec {
     Stack5W cc_mean[NS0], cc_scale[NS0], lrp[NS0], cc_mean_p[NS0], cc_scale_p[NS0], lrp_p[NS0];
     float* medians = nullptr;                    // [192] device
     const float* cust_map = nullptr;             // pc_codec_set_cust_map: consumed by the next compress / decompress call
+    const float* rem_ckpt = nullptr;             // pc_codec_set_rem_checkpoint: NCHW [B][320][HW] representation for the REM nets' x_base input (next call)
+    int rem_mu_std = 0;                          // the loaded post_latent nets are the mu_std=True form (2N-channel enhancement branch and output)
     float* eb_net = nullptr;                     // [192][PC_EB_NET_FLOATS] device: density network of the EntropyBottleneck (forward path)
     float* scale_table = nullptr;                // [64] device
     int n_table = 0;
@@ -979,6 +981,11 @@ extern "C" int pc_codec_finalize(pc_codec* c)
         while (levels < 3 && c->sd.count("post_latent." + std::to_string(levels) + ".0.enc.0.conv1.weight")) ++levels;
         if (levels) {
             const int n_sub = c->sd.count("post_latent.0.0.enc_base_rep.2.conv1.weight") ? 3 : 2;
+            {   // mu_std=True nets take cat(mu, scale) in the enhancement-parameter branch: conv1 weight [N][2N][3][3] (CHProgREM.py:30,46)
+                auto it = c->sd.find("post_latent.0.0.enc_enh_entropy_params.0.conv1.weight");
+                c->rem_mu_std = (it != c->sd.end() && it->second.shape.size() == 4 && it->second.shape[1] == 2 * SLICE) ? 1 : 0;
+            }
+            const int e_in = c->rem_mu_std ? 2 * SLICE : SLICE, e_out = c->rem_mu_std ? 2 * SLICE : SLICE;
             c->rem.assign((size_t)levels * NS0, LrrW{});
             for (int k = 0; k < levels; ++k)
                 for (int i = 0; i < NS0; ++i) {
@@ -988,11 +995,11 @@ extern "C" int pc_codec_finalize(pc_codec* c)
                     for (int j = 0; j < n_sub; ++j) {
                         const std::string js = "." + std::to_string(j);
                         PCCHK(load_rb(c, p + "enc_base_entropy_params" + js, j == 0 ? 2 * SLICE : SLICE, SLICE, &L.ent_base[j]));
-                        PCCHK(load_rb(c, p + "enc_enh_entropy_params" + js, SLICE, SLICE, &L.ent_enh[j]));
+                        PCCHK(load_rb(c, p + "enc_enh_entropy_params" + js, j == 0 ? e_in : SLICE, SLICE, &L.ent_enh[j]));
                         PCCHK(load_rb(c, p + "enc_base_rep" + js, SLICE, SLICE, &L.base_rep[j]));
                     }
                     for (int j = 0; j < L.n_enc; ++j)
-                        PCCHK(load_rb(c, p + "enc." + std::to_string(j), j == 0 ? 3 * SLICE : 2 * SLICE, j == L.n_enc - 1 ? SLICE : 2 * SLICE, &L.enc[j]));
+                        PCCHK(load_rb(c, p + "enc." + std::to_string(j), j == 0 ? 3 * SLICE : 2 * SLICE, j == L.n_enc - 1 ? e_out : 2 * SLICE, &L.enc[j]));
                 }
             c->rem_levels_loaded = levels;
         }
@@ -1034,6 +1041,14 @@ extern "C" int pc_codec_set_cust_map(pc_codec* c, const float* cust_map)
 {
     if (!c) return PC_ERR_ARG;
     c->cust_map = cust_map;
+    return PC_OK;
+}
+
+extern "C" int pc_codec_set_rem_checkpoint(pc_codec* c, const float* rep)
+{
+    // checkpoint_rep of PostRateProcessedNetwork.compress / decompress (CHProgREM.py:676,773 / :901,989): consumed by the next call
+    if (!c) return PC_ERR_ARG;
+    c->rem_ckpt = rep;
     return PC_OK;
 }
 
@@ -1087,6 +1102,7 @@ struct ChainCtx {
     int level;                                  // enhancement strings of this level sit at slot 10 + 10*level + i
     float* lik; int lik_nch;                    // forward path: y likelihoods, NCHW [B][lik_nch][HW] (null otherwise)
     const float* cust_map;                      // NCHW [B][320][HW]: enhancement masks threshold this map instead of the scale
+    const float* rem_ckpt;                      // NCHW [B][320][HW] or null: x_base input of the REM nets instead of the decoded base slices
     hipEvent_t* sig;                            // if set: record sig[i] on the lane's stream once slice i (of this pass) is complete
     SliceSignal* sig_count;                     //         ... and publish the number of recorded events to other host threads
     hipEvent_t* waitv;                          // if set: slice i of this pass starts only after waitv[i] (recorded by the other chain)
@@ -1159,7 +1175,7 @@ int rem_rb(hipStream_t st, const RbW& r, std::initializer_list<Seg> segs, const 
 
 // apply_latent_enhancement (CHProgREM.py:375-428) + LatentRateReduction.forward (:74-86) for enhancement slice i, images [b0, b0+nb):
 // the predicted scale sc_i [nb*HW][32] is refined in place.  mu_std = False: the means are left alone.
-int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_t st, const std::string& tag)
+int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* mu_i, float* sc_i, hipStream_t st, const std::string& tag)
 {
     pc_codec* c = k.c;
     const double q = k.quality;
@@ -1194,15 +1210,23 @@ int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_
     const float* yb_i = img(k.yb, b0, pi * D0) + 32 * i;
     const float* mu_b = k.mu + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;       // base step i: mu / scale kept per slice
     const float* sd_b = k.scale + (size_t)i * k.M * SLICE + (size_t)b0 * pi * SLICE;
-    // f_ent_prog = enc_enh_entropy_params(scale)
+    // f_ent_prog = enc_enh_entropy_params(scale), or of cat(mu, scale) in the mu_std form (:789)
     const float* x = sc_i; int ldx = SLICE;
     for (int j = 0; j < L.n_sub; ++j) {
         float* o = j == L.n_sub - 1 ? fp : (j & 1 ? pb : pa);
-        PCCHK(rem_rb(st, L.ent_enh[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
+        if (j == 0 && c->rem_mu_std) PCCHK(rem_rb(st, L.ent_enh[0], {{mu_i, SLICE, SLICE}, {sc_i, SLICE, SLICE}}, nullptr, 0, B, h, w, t1, ts, o));
+        else PCCHK(rem_rb(st, L.ent_enh[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
         x = o; ldx = SLICE;
     }
-    // f_latent = enc_base_rep(y_b_hat)
+    // f_latent = enc_base_rep(y_b_hat); y_b_hat = the decoded base slice, or the caller's checkpoint representation (:773,989), which
+    // arrives NCHW and is transposed to the chain's NHWC here
     x = yb_i; ldx = D0;
+    if (k.rem_ckpt) {
+        float* ck;
+        PCCHK(c->buf("rem_ck" + tag, m * 32, &ck));
+        PCCHK(pc_nchw_slice_to_nhwc_launch(k.rem_ckpt + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi, (int64_t)D0 * (int64_t)pi, nb, (int)pi, SLICE, ck, st));
+        x = ck; ldx = SLICE;
+    }
     for (int j = 0; j < L.n_sub; ++j) {
         float* o = j == L.n_sub - 1 ? fl : (j & 1 ? pb : pa);
         PCCHK(rem_rb(st, L.base_rep[j], {{x, ldx, SLICE}}, x, ldx, B, h, w, t1, ts, o));
@@ -1225,7 +1249,8 @@ int rem_refine(const ChainCtx& k, int i, int b0, int nb, float* sc_i, hipStream_
         PCCHK(rem_rb(st, L.enc[j], {{x, ci, ci}}, x, ci, B, h, w, t1, ts, o));
         x = o;
     }
-    // scale <- ret * att + scale   (:81-85)
+    // scale <- ret * att + scale   (:81-85); mu_std: ret has 2N channels, (mu, scale) <- ret * cat(att, att) + cat(mu, scale)   (:397-398,414-416)
+    if (c->rem_mu_std) return pc_rem_combine_launch(x, 2 * SLICE, sc_i, SLICE, nb, k.HW, thr2, mode_star, thr2 + k.B, mode_bar, st, mu_i, SLICE);
     return pc_rem_combine_launch(x, SLICE, sc_i, SLICE, nb, k.HW, thr2, mode_star, thr2 + k.B, mode_bar, st);
 }
 
@@ -1249,7 +1274,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
             const int i = step - NS0, s = std::min(5, i);
             PCCHK(stack5_pair(c, sA, c->cc_mean_p[i], c->cc_scale_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}},
                               ls + D0, nb, k.h, k.w, mu_i, sc_i, tm.c_str(), ts.c_str()));
-            PCCHK(rem_refine(k, i, b0, nb, sc_i, sA, tag));                           // REM: refined scale before the mask (CHProgREM.py:812-826)
+            PCCHK(rem_refine(k, i, b0, nb, mu_i, sc_i, sA, tag));                           // REM: refined scale before the mask (CHProgREM.py:812-826)
             if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sA, tag));
         }
         return PC_OK;
@@ -1264,7 +1289,8 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
         const int i = step - NS0, s = std::min(5, i);
         PCCHK(stack5(c, sA, c->cc_mean_p[i], {{lm + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, mu_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, tm.c_str()));
         PCCHK(stack5(c, sB, c->cc_scale_p[i], {{ls + D0, MLAT, D0}, {yb + 32 * i, D0, 32}, {ye + 32 * (i - s), D0, 32 * s}}, nb, k.h, k.w, sc_i, SLICE, PC_EPI_NONE, nullptr, 0, nullptr, 0, ts.c_str()));
-        PCCHK(rem_refine(k, i, b0, nb, sc_i, sB, tag));
+        if (two && c->rem_n && c->rem_mu_std) { HIPCHK(hipEventRecord(eA, sA)); HIPCHK(hipStreamWaitEvent(sB, eA, 0)); }   // the refinement reads (and rewrites) mu, which stream A has just produced
+        PCCHK(rem_refine(k, i, b0, nb, mu_i, sc_i, sB, tag));
         if (k.mode == 1) PCCHK(mask_threshold(k, i, b0, nb, sc_i, sB, tag));   // :819-824
     }
     if (two) { HIPCHK(hipEventRecord(eB, sB)); HIPCHK(hipStreamWaitEvent(sA, eB, 0)); }
@@ -1565,6 +1591,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     PCCHK(c->buf("idx", M * SLICE * 2 * NS0, &k.idx));
     k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
     k.cust_map = c->cust_map; c->cust_map = nullptr;
+    k.rem_ckpt = c->rem_ckpt; c->rem_ckpt = nullptr;
 
     const size_t n_half = (size_t)NS0 * M * SLICE, n_z = (size_t)B * ZHW * NCH;      // symbols of one pass / of z
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
@@ -1896,6 +1923,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     PCCHK(c->buf("idx8", M * SLICE * 2 * NS0, &k.idx8));
     k.c = c; k.B = B; k.h = h; k.w = w; k.HW = HW; k.M = M;
     k.cust_map = c->cust_map; c->cust_map = nullptr;
+    k.rem_ckpt = c->rem_ckpt; c->rem_ckpt = nullptr;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
     PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
     const int nt = c->n_threads == 1 ? 1 : 0;

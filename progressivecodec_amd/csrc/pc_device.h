@@ -123,8 +123,11 @@ size_t pc_quantile_work_bytes(int B);
 
 // REM (models/CHProgREM.py:84-86,395-401): scale <- ret * round(star - bar) + scale, the two masks thresholding the UNREFINED scale
 // (mode 1: value >= thr[b]; 2: ones; 3: zeros).  ret / scale NHWC [B][HW][32] with pixel strides.
+// mu != null: the mu_std form -- ret has 2N channels per pixel, mu <- ret[:N] * att + mu as well (:397-398,414-416)
 int pc_rem_combine_launch(const float* ret, int ld_ret, float* scale, int ld_scale, int B, int HW, const float* thr_star, int mode_star,
-                          const float* thr_bar, int mode_bar, hipStream_t stream);
+                          const float* thr_bar, int mode_bar, hipStream_t stream, float* mu = nullptr, int ld_mu = 0);
+// one C-channel slice of an NCHW tensor (element (b, c, p) at src[b * batch_stride + c * HW + p]) -> NHWC [B][HW][C]
+int pc_nchw_slice_to_nhwc_launch(const float* src, int64_t batch_stride, int B, int HW, int C, float* dst, hipStream_t stream);
 
 int pc_eb_quant_launch(const float* z, int B, int HW, int C, const float* medians, int32_t* sym, float* zhat,
                        hipStream_t stream);

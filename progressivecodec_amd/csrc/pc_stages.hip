@@ -716,9 +716,11 @@ __global__ void eb_dequant_kernel(const int32_t* __restrict__ sym, int B, int HW
     }
 }
 
-// REM: refined scale = ret * att + scale, att = round(star - bar) with both masks taken on the unrefined scale (CHProgREM.py:395-401, :84-86)
+// REM: refined scale = ret * att + scale, att = round(star - bar) with both masks taken on the unrefined scale (CHProgREM.py:395-401, :84-86).
+// mu != null (mu_std=True, :397-398,414-416): ret carries 2N channels per pixel -- mu <- ret[:N] * att + mu, scale <- ret[N:] * att + scale.
 __global__ void rem_combine_kernel(const float* __restrict__ ret, int ld_ret, float* __restrict__ scale, int ld_scale, int B, int HW,
-                                   const float* __restrict__ thr_star, int mode_star, const float* __restrict__ thr_bar, int mode_bar)
+                                   const float* __restrict__ thr_star, int mode_star, const float* __restrict__ thr_bar, int mode_bar,
+                                   float* __restrict__ mu, int ld_mu)
 {
     const int64_t n = (int64_t)B * HW * 32;
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -729,7 +731,22 @@ __global__ void rem_combine_kernel(const float* __restrict__ ret, int ld_ret, fl
         const float star = mode_star == 1 ? (s >= thr_star[b] ? 1.0f : 0.0f) : (mode_star == 2 ? 1.0f : 0.0f);
         const float bar = mode_bar == 1 ? (s >= thr_bar[b] ? 1.0f : 0.0f) : (mode_bar == 2 ? 1.0f : 0.0f);
         const float att = pc_roundevenf(star - bar);
-        scale[pix * ld_scale + c] = ret[pix * ld_ret + c] * att + s;
+        if (mu) {
+            mu[pix * ld_mu + c] = ret[pix * ld_ret + c] * att + mu[pix * ld_mu + c];
+            scale[pix * ld_scale + c] = ret[pix * ld_ret + 32 + c] * att + s;
+        } else scale[pix * ld_scale + c] = ret[pix * ld_ret + c] * att + s;
+    }
+}
+
+// one 32-channel slice of an NCHW tensor -> NHWC [B][HW][C] (the REM's checkpoint representation arrives NCHW)
+__global__ void nchw_slice_to_nhwc_kernel(const float* __restrict__ src, int64_t sb, int B, int HW, int C, float* __restrict__ dst)
+{
+    const int64_t n = (int64_t)B * HW * C;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        const int64_t pix = e / C;
+        const int b = (int)(pix / HW), hw = (int)(pix - (int64_t)b * HW);
+        dst[e] = src[(int64_t)b * sb + (int64_t)c * HW + hw];
     }
 }
 
@@ -873,11 +890,20 @@ int pc_eb_dequant_launch(const int32_t* sym, int B, int HW, int C, const float* 
 }
 
 int pc_rem_combine_launch(const float* ret, int ld_ret, float* scale, int ld_scale, int B, int HW, const float* thr_star, int mode_star,
-                          const float* thr_bar, int mode_bar, hipStream_t stream)
+                          const float* thr_bar, int mode_bar, hipStream_t stream, float* mu, int ld_mu)
 {
     if (!ret || !scale || B <= 0 || HW <= 0 || (mode_star == 1 && !thr_star) || (mode_bar == 1 && !thr_bar)) return PC_ERR_ARG;
     const int64_t n = (int64_t)B * HW * 32;
     const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
-    hipLaunchKernelGGL(rem_combine_kernel, dim3(blocks), dim3(256), 0, stream, ret, ld_ret, scale, ld_scale, B, HW, thr_star, mode_star, thr_bar, mode_bar);
+    hipLaunchKernelGGL(rem_combine_kernel, dim3(blocks), dim3(256), 0, stream, ret, ld_ret, scale, ld_scale, B, HW, thr_star, mode_star, thr_bar, mode_bar, mu, ld_mu);
+    return PC_LAUNCH_CHECK();
+}
+
+int pc_nchw_slice_to_nhwc_launch(const float* src, int64_t batch_stride, int B, int HW, int C, float* dst, hipStream_t stream)
+{
+    if (!src || !dst || B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
+    const int64_t n = (int64_t)B * HW * C;
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(nchw_slice_to_nhwc_kernel, dim3(blocks), dim3(256), 0, stream, src, batch_stride, B, HW, C, dst);
     return PC_LAUNCH_CHECK();
 }

@@ -3,9 +3,13 @@
 slice is refined by a small CNN (``LatentRateReduction``, :12-86) before the variance mask is taken (``apply_latent_enhancement``,
 :375-428) -- three sets of ten CNNs, one set per range of quality between the ``check_levels``.
 
-Same constructor keywords, ``load_state_dict(state_dict_base, state_dict_post)``, ``compress`` / ``decompress`` signatures and return
-dictionaries as the reference (``real_compress=True``, ``checkpoint_rep=None``, ``mu_std=False``: what its compress_with_ac-style
-evaluation uses).  All arithmetic runs in the native codec (libpcodec.so: ``pc_codec_set_rem``); nothing here computes.
+Same constructor keywords (``check_levels``, ``mu_std``, ``dimension``, ``escalation``), ``load_state_dict(state_dict_base,
+state_dict_post)``, ``compress`` / ``decompress`` signatures and return dictionaries as the reference (``real_compress=True``).
+``mu_std=True``: the nets take cat(mu, scale) and refine the predicted mean as well (:30,42,397-416).  ``dimension="middle"``: two
+ResidualBlocks per sub-net instead of three (:23-43).  ``checkpoint_rep``: a [B,320,h,w] representation that replaces the decoded base
+slices as the nets' x_base input (:773,989); ``extract_chekpoint_representation_from_images`` (sic, :335-373) chains the check levels
+through it when ``escalation=True``.  All arithmetic runs in the native codec (libpcodec.so: ``pc_codec_set_rem``,
+``pc_codec_set_rem_checkpoint``); nothing here computes.
 """
 import ctypes as C
 
@@ -20,8 +24,6 @@ class PostRateProcessedNetwork:
     def __init__(self, base_net, check_levels=(0.01, 0.25, 1.75), mu_std=False, dimension="big", escalation=False):
         if not isinstance(base_net, ChannelProgresssiveWACNN):
             raise AssertionError("base_net must be a ChannelProgresssiveWACNN")               # CHProgREM.py:224
-        if mu_std or escalation:
-            raise NotImplementedError("mu_std / escalation variants of the REM are not implemented (SURVEY.md section 8f)")
         if not 1 <= len(check_levels) <= 3:
             raise ValueError("one to three check levels")
         self.base_net = base_net
@@ -37,7 +39,7 @@ class PostRateProcessedNetwork:
         """CHProgREM.py:361-369: the base codec's state dict and, optionally, post_latent's."""
         extra = None
         if state_dict_post is not None:
-            spec = rem_param_spec(self.check_multiple, self.dimension)
+            spec = rem_param_spec(self.check_multiple, self.dimension, mu_std=self.mu_std)
             missing = [k for k in spec if k not in state_dict_post]
             if missing:
                 # (the native REM needs every post_latent tensor whatever `strict` says: a CNN with absent weights cannot run; the
@@ -60,20 +62,40 @@ class PostRateProcessedNetwork:
     def update(self, *a, **kw):
         return self.base_net.update(*a, **kw)
 
-    def _on(self):
+    def _on(self, checkpoint_rep=None):
         if self._post is None:
             raise ValueError("load_state_dict(state_dict_base, state_dict_post) first: the REM needs its post_latent weights")
         lv = (C.c_double * self.check_multiple)(*self.check_levels)
         check(lib().pc_codec_set_rem(self.base_net._h, lv, self.check_multiple), "pc_codec_set_rem")
+        if checkpoint_rep is not None:                                      # CHProgREM.py:773,989
+            import torch
+            rep = checkpoint_rep.to(self.base_net.device, torch.float32).contiguous()
+            if rep.dim() != 4 or rep.shape[1] != 320:
+                raise ValueError("checkpoint_rep must be [B, 320, H/16, W/16]")
+            self._rep = rep                                                 # kept alive until the call has consumed it
+            check(lib().pc_codec_set_rem_checkpoint(self.base_net._h, C.c_void_p(rep.data_ptr())), "pc_codec_set_rem_checkpoint")
+
+    def extract_chekpoint_representation_from_images(self, x, quality, rc=True):
+        """CHProgREM.py:335-373 (name as in the reference): the y_hat a coder of `quality` produced -- with escalation=True, chained
+        through the check levels below it, each level's nets reading the representation of the level before."""
+        if not self.escalation:
+            return self.compress(x, quality=quality, mask_pol="point-based-std", real_compress=rc)["y_hat"]
+        rep = self.compress(x, quality=self.check_levels[0], mask_pol="point-based-std", real_compress=rc)["y_hat"]
+        if quality == self.check_levels[0]:
+            return rep
+        rep1 = self.compress(x, quality=self.check_levels[1], mask_pol="point-based-std", checkpoint_rep=rep, real_compress=rc)["y_hat"]
+        if quality == self.check_levels[1]:
+            return rep1
+        return self.compress(x, quality=self.check_levels[2], mask_pol="point-based-std", checkpoint_rep=rep1, real_compress=rc)["y_hat"]
 
     def _off(self):
         check(lib().pc_codec_set_rem(self.base_net._h, None, 0), "pc_codec_set_rem")
 
     def compress(self, x, quality=0.0, mask_pol="point-based-std", checkpoint_rep=None, real_compress=True, used_qual=None):
         """CHProgREM.py:673-888 -> {"strings", "shape", "masks", "y_hat"}."""
-        if checkpoint_rep is not None or not real_compress:
-            raise NotImplementedError("checkpoint_rep / real_compress=False (training-time representations) are out of scope")
-        self._on()
+        if not real_compress:
+            raise NotImplementedError("real_compress=False (the training-time quantiser without entropy coding) is out of scope")
+        self._on(checkpoint_rep)
         try:
             out = self.base_net.compress(x, quality, mask_pol)
             out["y_hat"] = self.base_net.read_latent("yhat_enh" if quality > 0 else "yhat_base", x.shape[0], x.shape[2] // 16, x.shape[3] // 16)
@@ -84,9 +106,7 @@ class PostRateProcessedNetwork:
     def decompress(self, strings, shape, quality, mask_pol=None, checkpoint_rep=None, timing=False, used_qual=None):
         """CHProgREM.py:896-1126 -> {"x_hat", "y_hat", "time"}."""
         import time
-        if checkpoint_rep is not None:
-            raise NotImplementedError("checkpoint_rep is out of scope")
-        self._on()
+        self._on(checkpoint_rep)
         try:
             t0 = time.time()
             out = self.base_net.decompress(strings, shape, quality, mask_pol)

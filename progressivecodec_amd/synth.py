@@ -135,13 +135,13 @@ def synthetic_state_dict(cfg: CodecConfig = CodecConfig(), seed: int = 0, as_tor
     return out
 
 
-def synthetic_post_state_dict(check_multiple: int = 3, dimension: str = "big", seed: int = 0, as_torch: bool = True):
+def synthetic_post_state_dict(check_multiple: int = 3, dimension: str = "big", seed: int = 0, as_torch: bool = True, mu_std: bool = False):
     """Deterministic weights for PostRateProcessedNetwork.post_latent (reference models/CHProgREM.py:227-234) in its own state-dict
     layout ("<level>.<slice>.<subnet>.<block>.conv1.weight" ...).  Fan-in scaled; the last block of `enc` is damped so that the
     refinement moves the predicted scale by a fraction of itself (an untrained net would otherwise swamp it)."""
     from .arch import rem_param_spec
     out = OrderedDict()
-    for name, (shape, dtype, kind) in rem_param_spec(check_multiple, dimension).items():
+    for name, (shape, dtype, kind) in rem_param_spec(check_multiple, dimension, mu_std=mu_std).items():
         g = _rng("post_latent." + name, seed)
         if kind == "conv_w":
             co, ci, kh, kw = shape

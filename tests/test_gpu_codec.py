@@ -1004,3 +1004,63 @@ def test_config3_kodak_sized_set_all_13_levels():
                   f"psnr {p_here:.6f} (ref {lv['psnr']:.6f})")
     print(f"Config 3: {n_ff}/26 (image, level) pairs flip-free against the reference; RD table (24 images) bpp {[round(v, 4) for v in bpp]} psnr {[round(v, 4) for v in psnr]}")
     assert n_ff >= 6
+
+
+_REM_VARIANT_NETS = {}
+
+
+def _rem_variant_gpu(c):
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from progressivecodec_amd.rem import PostRateProcessedNetwork
+    from progressivecodec_amd.synth import synthetic_post_state_dict
+    from tests.util import synth_sd
+    key = (c["mu_std"], c["dimension"], c["escalation"])
+    if key not in _REM_VARIANT_NETS:
+        net = PostRateProcessedNetwork(ChannelProgresssiveWACNN(device="cuda:0"), check_levels=c["check_levels"], mu_std=c["mu_std"],
+                                       dimension=c["dimension"], escalation=c["escalation"])
+        net.load_state_dict(synth_sd(), synthetic_post_state_dict(3, c["dimension"], mu_std=c["mu_std"]))
+        _REM_VARIANT_NETS[key] = net
+    return _REM_VARIANT_NETS[key]
+
+
+@pytest.mark.parametrize("idx", range(6))
+def test_rem_variants_bit_exact_vs_oracle_and_reference_goldens(idx):
+    """PostRateProcessedNetwork with mu_std=True (the mean refined too), dimension="middle" and escalation / checkpoint_rep
+    (CHProgREM.py:15-70, 335-373, 397-416, 773, 989): GPU == contract oracle on every string, mask, the refined mu and scale and x_hat;
+    against the REAL reference's fixture (tests/golden/rem_variants.json): hyper-latent strings and shapes identical, flip-free cases
+    identical in bytes and within 1e-4 dB."""
+    from tests.test_oracle_vs_golden import _rem_variant_cases, rem_variant_oracle, rem_variant_rep
+    c = _rem_variant_cases()[idx]
+    x = inputs(c["B"], c["H"], c["W"], c["seed"], c["kind"])
+    net = _rem_variant_gpu(c)
+    orc = rem_variant_oracle(c, "cdet")
+    rep_o = rem_variant_rep(orc, c, x)
+    rep_g = None
+    if c["escalation"]:
+        rep_g = net.extract_chekpoint_representation_from_images(x.cuda(), c["checkpoint_quality"])
+        assert np.array_equal(rep_g.cpu().numpy().view(np.uint32), rep_o.numpy().view(np.uint32)), "checkpoint representation differs from the oracle's"
+    out = net.compress(x.cuda(), c["quality"], "point-based-std", checkpoint_rep=rep_g)
+    taps = {}
+    orc.set_checkpoint_rep(rep_o)
+    ref = orc.compress(x, c["quality"], taps=taps)
+    assert out["strings"][1] == ref["strings"][1]
+    for s_, (a, b) in enumerate(zip(out["strings"][0], ref["strings"][0])):
+        assert a == b, f"y strings of slice {s_} differ"
+    for m, rm in zip(out["masks"], ref["masks"]):
+        assert np.array_equal(m.cpu().numpy(), rm.numpy())
+    for name in ("scale", "mu"):
+        t = net.base_net.read_tap(name).reshape(20, c["B"], -1, 32)[13]                      # refined parameters of enhancement slice 3, NHWC
+        assert np.array_equal(t.reshape(c["B"], c["H"] // 16, c["W"] // 16, 32).transpose(0, 3, 1, 2), taps["e3"][name].numpy()), name
+    dec = net.decompress(out["strings"], out["shape"], c["quality"], "point-based-std", checkpoint_rep=rep_g)
+    orc.set_checkpoint_rep(rep_o)
+    rdec = orc.decompress(ref["strings"], ref["shape"], c["quality"])["x_hat"]
+    assert np.array_equal(dec["x_hat"].cpu().numpy().view(np.uint32), rdec.numpy().view(np.uint32))
+    assert [sha(s) for s in out["strings"][1]] == c["z_sha"] and list(out["shape"]) == c["shape"]
+    first = flip_report(out["strings"][0], c["y_sha"], c["B"])
+    flip_free = all(f is None for f in first)
+    psnr = psnr_of(x, dec["x_hat"].cpu().clamp(0, 1))
+    print(f"{c['case']} q={c['quality']}: first diverging slice per image {first}; psnr {psnr:.6f} (ref {c['psnr']:.6f})")
+    if flip_free:
+        assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
+    assert abs(psnr - c["psnr"]) <= (NORTH_STAR_PSNR_TOL_DB if flip_free else 5e-2)
+    assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) <= (0 if flip_free else 2e-2 * c["bpp"])
