@@ -985,7 +985,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TM * TN == 
                     if (DIRECT) ro = (uint32_t)(8 * q + e) * sx4;
                     else ro = e == 0 ? rcur.x : (e == 1 ? rcur.y : (e == 2 ? rcur.z : rcur.w));
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rs_out, (int)(ro + lane_off), 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);                   // one element at a time: interleaved, the 16 GELUs cost 20 VGPRs (one wave per SIMD less)
+                    __builtin_amdgcn_sched_barrier(0);                   // one element at a time: interleaved, the 16 GELUs cost 20 VGPRs (one wave per SIMD less); letting the
+                                                                         // one-workgroup-per-CU instantiation interleave them changed nothing (profiles/r03_o_*)
                 }
                 if (!DIRECT && q < 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(rq) :: "memory");
             }
