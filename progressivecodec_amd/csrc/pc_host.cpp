@@ -523,7 +523,7 @@ extern "C" int pc_rans_decode_batch_u8(const uint8_t* const* encoded, const size
                                     n_threads);
 }
 
-extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.2 (gfx950), numeric contract 0x00020001"; }
+extern "C" const char* pc_version(void) { return "progressivecodec_amd 0.3 (gfx950), numeric contract 0x00020001"; }
 extern "C" uint32_t pc_contract_id(void) { return PC_NUMERIC_CONTRACT_ID; }
 
 extern "C" const char* pc_strerror(int code)
