@@ -33,6 +33,20 @@ def test_bench_line_contract():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
+    # round 3: the serial schedule beside the overlapped one, the host entropy coder's rates, the parity figure against the reference itself
+    assert j["sequential_value"] and 0 < j["sequential_value"] <= 1.02 * j["value"]
+    assert "overlapped_schedule" in r and "rank_ms_per_step" in j
+    rp = j["reference_parity"]
+    assert rp["source"] and rp["source"].startswith("tests/golden/config2.json") and rp["north_star_tolerance_db"] == 1e-4
+    for k in ("z_strings_identical", "y_strings_identical", "flip_free_images", "first_diverging_slice_histogram", "max_abs_psnr_diff_db_flip_free_images"):
+        assert k in rp, k
+    assert rp["max_abs_psnr_diff_db_flip_free_images"] <= 1e-4
+    rn = j["rans"]
+    for cfg in ("config2", "config5_frame"):
+        for k in ("encode_msym_s_per_stream", "decode_msym_s_per_stream", "streams_in_flight", "pool_threads", "host_encode_ms_exposed",
+                  "host_decode_ms_in_decompress_summed_over_chains", "symbols_per_stream"):
+            assert k in rn[cfg], (cfg, k)
+    assert rn["config5_frame"]["symbols_per_stream"] == 32 * 136 * 240
 
 
 def test_committed_profiles_belong_to_this_build():
@@ -40,8 +54,8 @@ def test_committed_profiles_belong_to_this_build():
     committed set must be that build's, or the driver's bench line at round end carries nulls."""
     from bench import newest_profile, source_hash
     src = source_hash()
-    import pytest
-    for pattern in ("r*_hbm_traffic.json", "r*_stage_kernels_rocprof.json"):
+    for pattern in ("r*_hbm_traffic.json", "r*_stage_kernels_rocprof.json", "r*_overlap_schedule_mfma.json", "r*_traffic_by_shape.json"):
         j, why = newest_profile(pattern, src)
-        if j is None:                       # kernel sources changed since the last profile round: a reminder, not a failure
-            pytest.skip(f"{why} -- re-run tools/profile_round.sh and commit its summaries before the round ends")
+        # a FAILURE (VERDICT r02 "What's weak" 11): kernel sources changed since the last profile round -- re-run
+        # `gpurun -- 'bash tools/profile_round.sh rNN_x'`, copy gpurun_out/profiles_rNN_x/* into profiles/ and commit
+        assert j is not None, f"{why} -- the driver's bench line would carry nulls"
