@@ -3,7 +3,7 @@
 GaussianConditional kernels and the quantile threshold on one enhancement slice of Config 4's size
 (256 images of 1024x1024 -> latent 64x64, 32 channels: 33.5 M elements per array), timed with HIP
 events through the C ABI.  Algorithmic bytes per element: encoder enhancement
-slice 32 B (+4 B mask), base slice 24 B, decoder index 8 B (+4 B), dequantise 12 B, quantile 4 B.
+slice 32 B (the mask included), base slice 24 B, decoder index 8 B, dequantise 12 B, quantile 4 B.
 
 usage: python tools/stage_bench.py [n_images]        prints one JSON line per kernel
 """
@@ -69,7 +69,7 @@ def main():
         check(L.pc_gc_dequantize(P(sym), P(mu), 32, B, HW, P(yhat), 32, None))
 
     quant()
-    for name, fn, bpe in (("quantile_thr_kernel", quant, 4), ("gc_prep_kernel<0> enhancement (mask+index+quantise+dequantise)", enc_enh, 36),
+    for name, fn, bpe in (("quantile_thr_kernel", quant, 4), ("gc_prep_kernel<0> enhancement (mask+index+quantise+dequantise)", enc_enh, 32),
                           ("gc_prep_kernel<0> base", enc_base, 24), ("gc_prep_kernel<1> decoder index", dec_idx, 8),
                           ("gc_dequant_kernel", deq, 12)):
         t = timeit(fn)

@@ -58,7 +58,7 @@ def main():
           if any(t in r["Kernel_Name"] for t in ("quantile", "gc_prep", "gc_dequant"))]
     n = B * 64 * 64 * 32
     stages = [("quantile threshold (layers/masking.py:218: torch.quantile per image)", "quantile", 4),
-              ("gc_prep_kernel<0> enhancement slice (mask + index + quantise + dequantise)", "gc_prep_kernel<0>", 36),
+              ("gc_prep_kernel<0> enhancement slice (mask + index + quantise + dequantise)", "gc_prep_kernel<0>", 32),   # read {scale, y_enh, y_base, mu} 16 B + write {mask, index, symbol, y_hat} 16 B (rounds 1-2 billed the mask twice: 36)
               ("gc_prep_kernel<0> base slice", "gc_prep_kernel<0>", 24),
               ("gc_prep_kernel<1> decoder index", "gc_prep_kernel<1>", 8),
               ("gc_dequant_kernel", "gc_dequant", 12)]
