@@ -108,6 +108,27 @@ def test_conv_bit_exact(case):
         f"max abs diff {np.abs(got - want).max()} mismatches {(got != want).sum()}/{got.size}"
 
 
+def _fuzz_conv_cases(n=48, seed=20261005):
+    """seeded random layer shapes: row tails (M not a multiple of 32 / 64), column tails (Cout not a multiple of 32), one to three
+    channel chunks, all kernel sizes / strides / activations the codec uses, permuted and plain row orders"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        k = int(rng.choice([1, 3, 3, 5]))
+        s = int(rng.choice([1, 1, 2])) if k > 1 else 1
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(1, 37)), int(rng.integers(1, 37))
+        ci = 16 * int(rng.integers(1, 13))
+        co = 4 * int(rng.integers(2, 60))
+        out.append((B, H, W, ci, co, k, s, int(rng.integers(0, 2)), 0))
+    return out
+
+
+@pytest.mark.parametrize("case", _fuzz_conv_cases())
+def test_conv_bit_exact_random_shapes(case):
+    """the unrolled epilogue forms of round 3 (direct / row-table, every tail) against the oracle on random layer shapes"""
+    test_conv_bit_exact(case)
+
+
 @pytest.mark.parametrize("case", [(2, 4, 4, 320, 192), (1, 8, 8, 192, 192), (2, 8, 8, 192, 3)])
 def test_deconv_bit_exact(case):
     L, check = _lib()
