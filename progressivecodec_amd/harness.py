@@ -70,10 +70,15 @@ def compute_padding(in_h, in_w, min_div=64):
     return (left, right, top, bottom), (-left, -right, -top, -bottom)
 
 
-def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda", shared_base=False):
+def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda", shared_base=False, batch_same_size=False):
     """images: iterable of [1,3,H,W] (or [3,H,W]) float tensors in [0,1].
     Returns (bpp[level], psnr[level], dec_time[level]) averaged over the images, as step.py:404 does,
     plus the per-image table.
+
+    batch_same_size=True (implies shared_base; beyond the reference, which loops over single images, step.py:297): images of equal
+    size are stacked and coded in one call per group -- an image codes identically alone and inside any batch (every image is its own
+    set of rANS streams, entropy_models.py:227; asserted by the GPU tests), so the RD table is the same table, rows in input order; the
+    slice chain then runs at M = n_images * H/16 * W/16 rows instead of one image's.  dec_time = group decode time / (images * levels).
 
     shared_base=True codes all levels of an image with model.compress_levels / decompress_levels: g_a, h_a, z, h_s and
     the ten base slices run once per image instead of once per level.  The RD table is
@@ -82,6 +87,38 @@ def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", de
     import torch.nn.functional as F
     pr_list = list(PR_LIST if pr_list is None else pr_list)
     rows = []
+    if batch_same_size:
+        imgs = [(x if x.dim() == 4 else x.unsqueeze(0)) for x in images]
+        groups = {}
+        for i, x in enumerate(imgs):
+            groups.setdefault((x.shape[2], x.shape[3]), []).append(i)
+        by_image = {}
+        with torch.no_grad():
+            for (h, w), idxs in groups.items():
+                xb = torch.cat([imgs[i] for i in idxs], 0).to(device)
+                pad, unpad = compute_padding(h, w, 64)
+                xp = F.pad(xb, pad, mode="constant", value=0)
+                datas = model.compress_levels(xp, pr_list, mask_pol=mask_pol)
+                if xb.is_cuda:
+                    torch.cuda.synchronize()
+                t0 = time.time()
+                outs = model.decompress_levels([d["strings"] for d in datas], datas[0]["shape"], pr_list, mask_pol=mask_pol)
+                if xb.is_cuda:
+                    torch.cuda.synchronize()
+                dec_time = (time.time() - t0) / (len(pr_list) * len(idxs))
+                for p, data, out_dec in zip(pr_list, datas, outs):
+                    x_hat = F.pad(out_dec["x_hat"], unpad).clamp_(0, 1)
+                    y_strings, z_strings = data["strings"]
+                    for b, i in enumerate(idxs):
+                        mse = torch.mean((xb[b:b + 1] - x_hat[b:b + 1]) ** 2).item()
+                        nbytes = sum(len(s[b]) for s in y_strings) + len(z_strings[b])
+                        by_image.setdefault(i, []).append({"quality": p, "bpp": 8.0 * nbytes / (h * w),
+                                                           "psnr": -10.0 * math.log10(mse) if mse > 0 else float("inf"), "dec_time": dec_time})
+        for i in range(len(imgs)):
+            rows.extend(by_image[i])
+        n_img = max(1, len(imgs))
+        avg = lambda key, p: sum(r[key] for r in rows if r["quality"] == p) / n_img
+        return ([avg("bpp", p) for p in pr_list], [avg("psnr", p) for p in pr_list], [avg("dec_time", p) for p in pr_list], rows)
     with torch.no_grad():
         for x in images:
             x = x if x.dim() == 4 else x.unsqueeze(0)

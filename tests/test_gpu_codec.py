@@ -1098,3 +1098,25 @@ def test_rem_variants_bit_exact_vs_oracle_and_reference_goldens(idx):
         assert [[int(m[b].sum().item()) for b in range(c["B"])] for m in out["masks"]] == c["mask_sums"]
     assert abs(psnr - c["psnr"]) <= (NORTH_STAR_PSNR_TOL_DB if flip_free else 5e-2)
     assert abs(bpp_of(out["strings"], c["B"], c["H"], c["W"]) - c["bpp"]) <= (0 if flip_free else 2e-2 * c["bpp"])
+
+
+def test_harness_batching_same_size_images_gives_the_same_rd_table():
+    """compress_with_ac(batch_same_size=True): images of equal size coded in one call per group -- the same RD rows, in input order, as one
+    image at a time (an image codes identically alone and inside a batch); on the Config-3 set it is the faster way through the curve."""
+    import time
+    from progressivecodec_amd.harness import PR_LIST, compress_with_ac, config3_images
+    net = gpu_codec()
+    imgs = [inputs(1, 64, 128, 41), inputs(1, 96, 72, 42, "smooth"), inputs(1, 64, 128, 43, "smooth"), inputs(1, 96, 72, 44)]
+    levels = [PR_LIST[i] for i in (0, 4, 9, 12)]
+    b1, p1, _, rows1 = compress_with_ac(net, imgs, levels, shared_base=True)
+    b2, p2, _, rows2 = compress_with_ac(net, imgs, levels, batch_same_size=True)
+    assert [r["quality"] for r in rows1] == [r["quality"] for r in rows2]
+    assert [r["bpp"] for r in rows1] == [r["bpp"] for r in rows2]
+    assert max(abs(a["psnr"] - b["psnr"]) for a, b in zip(rows1, rows2)) < 1e-5          # (means reduced on the GPU over different tensors)
+    assert b1 == b2
+    k3 = config3_images()
+    t0 = time.time(); compress_with_ac(net, k3, PR_LIST, shared_base=True); torch.cuda.synchronize(); t1 = time.time()
+    compress_with_ac(net, k3, PR_LIST, batch_same_size=True); torch.cuda.synchronize(); t2 = time.time()
+    mp = 24 * 512 * 768 * 13 / 1e6
+    print(f"Config 3 (24 images x 13 levels, encode + decode): one image at a time {t1 - t0:.2f} s ({mp / (t1 - t0):.1f} level-MP/s), "
+          f"same-size images batched {t2 - t1:.2f} s ({mp / (t2 - t1):.1f} level-MP/s)")
