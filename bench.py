@@ -217,7 +217,7 @@ def main():
             for _ in range(n):
                 res = step()
             return res
-        qu, box = queue.Queue(maxsize=2), {}
+        qu, box = queue.Queue(maxsize=int(os.environ.get("PC_BENCH_QDEPTH", "2"))), {}
 
         def decoder():
             try:

@@ -649,8 +649,11 @@ int mask_mode_for(int mask_pol, double quality, float* q_out)
 int hyper(pc_codec* c, hipStream_t st, const float* z_hat, int B, int zh, int zw, double quality, float* lm, float* ls)
 {
     // h_scale_s[k] / h_mean_s[k] (CHProg_cnn.py:705-715) all read z_hat and nothing else: their first layers have ~110 workgroups
-    // each on 256 CUs, so the two (base only) or four nets run side by side on their own streams with their own workspaces.
-    static const bool par = [] { const char* v = std::getenv("PC_HYPER_PARALLEL"); return !v || std::atoi(v) != 0; }();
+    // each on 256 CUs, so the two (base only) or four nets CAN run side by side on their own streams with their own workspaces
+    // (PC_HYPER_PARALLEL=1).  That was worth 1 % in round 1; with the encoder / decoder objects side by side and the chains pipelined it costs
+    // 3 % of the overlapped bench and 2-5 % of the sequential one (profiles/r03_t_hyper_parallel_ab.log): four more streams' launches in a
+    // chip that is already shared by four chains.  Default off since round 3.
+    static const bool par = [] { const char* v = std::getenv("PC_HYPER_PARALLEL"); return v && std::atoi(v) != 0; }();
     const int n = quality != 0 ? 4 : 2;
     if (!par || c->profile) {
         PCCHK(hs(c, st, c->hss[0], z_hat, B, zh, zw, ls, MLAT));
@@ -1618,7 +1621,10 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     // out one by one (side stream) and coded while the rest of the chain still runs; only the last slice's coding is exposed.
     int last_coded = -1, first_coded = -1;
     for (int l = 0; l < n_levels; ++l) if (!(qualities[l] <= 0)) { last_coded = l; if (first_coded < 0) first_coded = l; }
-    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return v && std::atoi(v) != 0; }();
+    // Default OFF since round 3 (PC_NO_STREAMED_ENCODE=0 switches it on): the per-slice copies and events of the side stream cost the
+    // overlapped bench 3.4 % (46.7 -> 48.2 MP/s) and buy a sequential caller 0.6 ms of host coding per call -- nothing measurable
+    // (profiles/r03_t_streamed_encode_ab.log)
+    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return !v || std::atoi(v) != 0; }();
     const bool can_stream = !no_stream && lane_count(c, B, false) == 1;
     if (can_stream && !c->copy_stream) {
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));

@@ -29,7 +29,7 @@ run PC_GROUPED=0 PC_DUAL_STREAM=0 PC_LANES=1
 run PC_PIPELINE=0
 run PC_PIPELINE_DEC=0
 run PC_HOST_THREADS=1
-run PC_HYPER_PARALLEL=0 PC_NO_STREAMED_ENCODE=1
+run PC_HYPER_PARALLEL=1 PC_NO_STREAMED_ENCODE=0
 run GPU_MAX_HW_QUEUES=16
 echo "matrix failures: $fail"
 exit $fail
