@@ -12,16 +12,21 @@ through it when ``escalation=True``.  All arithmetic runs in the native codec (l
 ``pc_codec_set_rem_checkpoint``); nothing here computes.
 """
 import ctypes as C
+from collections import OrderedDict
 
 import numpy as np
 
 from ._lib import check, lib
 from .arch import rem_param_spec
-from .model import ChannelProgresssiveWACNN
+from .model import ChannelProgresssiveWACNN, _module_base
 
 
-class PostRateProcessedNetwork:
+class PostRateProcessedNetwork(_module_base()):
+    """A ``torch.nn.Module`` like the reference's (CHProgREM.py:205): ``base_net`` is a registered sub-module, ``state_dict()`` carries
+    ``base_net.*`` and ``post_latent.*`` as the reference's checkpoints do; the tensors are host copies of what was loaded."""
+
     def __init__(self, base_net, check_levels=(0.01, 0.25, 1.75), mu_std=False, dimension="big", escalation=False):
+        super().__init__()
         if not isinstance(base_net, ChannelProgresssiveWACNN):
             raise AssertionError("base_net must be a ChannelProgresssiveWACNN")               # CHProgREM.py:224
         if not 1 <= len(check_levels) <= 3:
@@ -32,8 +37,30 @@ class PostRateProcessedNetwork:
         self.mu_std, self.dimension, self.escalation = mu_std, dimension, escalation
         self._post = None
 
-    def eval(self):
-        return self
+    # ------------------------------------------------------------------ nn.Module surface
+    def to(self, *args, **kwargs):
+        return self                                                         # bound to base_net's HIP device
+
+    def forward(self, *args, **kwargs):
+        raise NotImplementedError("training forward() (CHProgREM.py:430-670) is out of scope")
+
+    def state_dict(self, *args, destination=None, prefix="", keep_vars=False):
+        import torch
+        out = OrderedDict() if destination is None else destination
+        self.base_net.state_dict(destination=out, prefix=prefix + "base_net.")
+        for k, a in (self._post or {}).items():
+            out[prefix + "post_latent." + k] = torch.from_numpy(np.array(a, copy=True))
+        return out
+
+    def named_parameters(self, prefix="", recurse=True, remove_duplicate=True):
+        import torch
+        yield from self.base_net.named_parameters(prefix=prefix + "base_net.")
+        for k, a in (self._post or {}).items():
+            yield prefix + "post_latent." + k, torch.nn.Parameter(torch.from_numpy(np.array(a, copy=True)), requires_grad=False)
+
+    def parameters(self, recurse=True):
+        for _, p in self.named_parameters():
+            yield p
 
     def load_state_dict(self, state_dict_base, state_dict_post=None, strict=False):
         """CHProgREM.py:361-369: the base codec's state dict and, optionally, post_latent's."""

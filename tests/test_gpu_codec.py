@@ -913,6 +913,25 @@ def test_rem_bit_exact_vs_oracle_and_reference_goldens(idx):
         assert plain["strings"][0][10:] != out["strings"][0][10:], "the refinement must change the enhancement strings"
 
 
+def test_rem_is_a_module_and_reloads_from_its_own_state_dict():
+    """CHProgREM.py:205: an nn.Module whose state_dict carries base_net.* and post_latent.* (the layout of the reference's REM
+    checkpoints); splitting it by prefix and loading it into a fresh object codes the same bytes."""
+    from progressivecodec_amd import ChannelProgresssiveWACNN, PostRateProcessedNetwork
+    from progressivecodec_amd.arch import rem_param_spec
+    net = _rem_gpu()
+    assert isinstance(net, torch.nn.Module) and isinstance(net.base_net, torch.nn.Module) and net.eval() is net and not net.training
+    sd = net.state_dict()
+    base = {k[len("base_net."):]: v for k, v in sd.items() if k.startswith("base_net.")}
+    post = {k[len("post_latent."):]: v for k, v in sd.items() if k.startswith("post_latent.")}
+    assert len(base) + len(post) == len(sd) and set(post) == set(rem_param_spec(3, "big")) and len(base) >= 1019
+    assert sum(p.numel() for p in net.parameters()) == sum(p.numel() for p in net.base_net.parameters()) + sum(v.numel() for v in post.values())
+    x = inputs(1, 64, 64, 5, "smooth").cuda()
+    want = net.compress(x, 0.5, "point-based-std")["strings"]
+    other = PostRateProcessedNetwork(ChannelProgresssiveWACNN(device="cuda:0"), check_levels=[0.01, 0.25, 1.75])
+    other.load_state_dict(base, post, strict=True)
+    assert other.compress(x, 0.5, "point-based-std")["strings"] == want
+
+
 def _golden_json(name):
     import json
     import os
