@@ -181,6 +181,17 @@ PC_API int pc_codec_set_scale_table(pc_codec* c, const float* table, int n);
 /* Validate that every tensor is present, fold the GDN re-parametrisation, pack weights into HBM. */
 PC_API int pc_codec_finalize(pc_codec* c);
 PC_API int pc_codec_set_threads(pc_codec* c, int n_threads);
+/* Schedule options of one codec object -- how the launch sequence is laid over streams and host threads, never what it computes (every
+ * byte string and x_hat is identical under every setting).  No reference counterpart (the reference is one stream, one thread).
+ *   "serial_schedule" 0 / 1   1: the whole chain on the caller's stream, one batch lane, no base || enhancement pipelining -- the form a
+ *                             profiler wants (a launch's duration is its own); default 0
+ *   "lanes_enc", "lanes_dec"  0 (default: 1 / 2) .. 8: sub-batches of compress / decompress that run on streams of their own
+ *   "host_threads"            as pc_codec_set_threads
+ *   "profile_in_schedule" 0/1 1: pc_codec_profile_begin only brackets the launches and leaves the schedule alone (default 0: profiling
+ *                             forces the serial schedule so that a launch's duration is its own)
+ * Unknown names and out-of-range values return PC_ERR_ARG.  The tuning switches of the profiling rounds (PC_CONV_*, PC_LANES ...) exist
+ * only in the -DPC_TUNING build of the library (csrc/Makefile `tuning`), not here. */
+PC_API int pc_codec_set_option(pc_codec* c, const char* name, int value);
 /* How the host entropy-coding pool of this process is laid out: threads = min(16, CPUs allowed by affinity and cgroup quota / local ranks),
  * pinned -- when there are several local ranks (LOCAL_WORLD_SIZE / LOCAL_RANK) -- to this rank's contiguous slice of the allowed CPUs
  * starting at first_cpu.  No reference counterpart (the reference codes on one thread under the GIL, entropy_models.py:226-235). */
@@ -200,8 +211,9 @@ PC_API int pc_codec_set_cust_map(pc_codec* c, const float* cust_map);
  * predicted scale of every enhancement slice is refined by a LatentRateReduction CNN (:12-86, apply_latent_enhancement :375-428) chosen
  * by the range [check_levels[k], check_levels[k+1]) the quality falls in.  The CNN weights are state-dict tensors named
  * "post_latent.<level>.<slice>.<subnet>.<block>.{conv1,conv2,skip}.{weight,bias}" set with pc_codec_set_tensor before
- * pc_codec_finalize.  n_levels in 1..3 switches the refinement on for the following compress / decompress / forward calls (mu_std =
- * False, no checkpoint_rep), 0 switches it off (plain ChannelProgresssiveWACNN). */
+ * pc_codec_finalize.  n_levels in 1..3 switches the refinement on for the following compress / decompress / forward calls, 0 switches it
+ * off (plain ChannelProgresssiveWACNN).  mu_std (:30,42,397-416) and dimension ("big" / "middle", :23-43) are properties of the loaded
+ * post_latent tensors (their names and shapes); checkpoint_rep is handed over with pc_codec_set_rem_checkpoint below. */
 PC_API int pc_codec_set_rem(pc_codec* c, const double* check_levels, int n_levels);
 /* checkpoint_rep of PostRateProcessedNetwork.compress / decompress (models/CHProgREM.py:676,773 / :901,989): a device tensor NCHW
  * [B][320][H/16][W/16] that replaces the decoded base slices as the x_base input of the LatentRateReduction nets in the NEXT compress /
@@ -262,6 +274,14 @@ PC_API int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_
 /* algorithmic HBM bytes (every operand of a launch once: input, weights, bias, output, aux tensors) summed over the launches recorded
  * since pc_codec_profile_begin; read it after pc_codec_profile_end */
 PC_API int pc_codec_profile_bytes(const pc_codec* c, double* total_algorithmic_bytes);
+/* In-schedule profile (option "profile_in_schedule"): the bracketed launches of one or several codec objects -- e.g. the encoder and the
+ * decoder object of progressivecodec_amd.CodecPipeline, which keep ~2.5 conv kernels in flight -- on ONE timeline.  pc_profile_set_epoch
+ * drains `device` and records the epoch; after pc_codec_profile_end, pc_codec_profile_intervals returns every recorded launch's start / end
+ * (ms since the epoch) and algorithmic FLOPs (cap entries available; all three arrays NULL: only *n is written).  bench.py folds the
+ * intervals of both objects: FLOPs / (time during which at least one conv kernel runs) = the in-situ MFMA fraction of the schedule it
+ * timed.  Measurement aids; no reference counterpart. */
+PC_API int pc_profile_set_epoch(int device);
+PC_API int pc_codec_profile_intervals(const pc_codec* c, double* t0_ms, double* t1_ms, double* flops, size_t cap, size_t* n);
 /* Host entropy-coding figures of the object's last compress / decompress call ("rANS: report Msym/s per stream
  * and streams in flight"; no reference counterpart -- the reference times decompress() as a whole, training/step.py:332-340).
  * out[0] wall ms of the last compress call, out[1] host ms spent in rANS encoding during it (mostly hidden behind the GPU chain),

@@ -60,7 +60,7 @@ struct GsW { WamW w0, w5; ConvW d1, d3, d6, d8; GdnW g2, g4, g7; };   // d8: the
 
 struct Tables {
     std::vector<int32_t> cdf, len, off;
-    std::vector<uint16_t> lut;                   // decoder start table per row (pc_host.h: DecTables)
+    std::vector<uint64_t> lut;                   // decoder start table per row (pc_host.h: DecTables)
     int n = 0, stride = 0;
     bool ok() const { return n > 0; }
     pc::DecTables dec() const { return pc::DecTables{cdf.data(), n, stride, len.data(), off.data(), lut.data()}; }
@@ -95,6 +95,7 @@ struct pc_codec {
     float* medians = nullptr;                    // [192] device
     const float* cust_map = nullptr;             // pc_codec_set_cust_map: consumed by the next compress / decompress call
     const float* rem_ckpt = nullptr;             // pc_codec_set_rem_checkpoint: NCHW [B][320][HW] representation for the REM nets' x_base input (next call)
+    int opt_serial = 0, opt_lanes_enc = 0, opt_lanes_dec = 0;   // pc_codec_set_option
     int rem_mu_std = 0;                          // the loaded post_latent nets are the mu_std=True form (2N-channel enhancement branch and output)
     float* eb_net = nullptr;                     // [192][PC_EB_NET_FLOATS] device: density network of the EntropyBottleneck (forward path)
     float* scale_table = nullptr;                // [64] device
@@ -118,10 +119,13 @@ struct pc_codec {
     int n_threads = 0;
     // optional per-launch profiling of the MFMA conv family (bench.py roofline leg)
     bool profile = false;
+    bool profile_in_schedule = false;             // pc_codec_set_option("profile_in_schedule"): brackets only -- the schedule stays what it is
+    bool serial_profile() const { return profile && !profile_in_schedule; }   // profiling that forces the chain onto the caller's stream
+    std::mutex prof_mu;                           // in-schedule profiling records from every host thread of the object
     std::vector<hipEvent_t> ev;
     size_t ev_used = 0;
     double prof_flops = 0.0, prof_bytes = 0.0;
-    struct ProfRec { int M, N, K, nphase, epi; double flops, bytes; };
+    struct ProfRec { int M, N, K, nphase, epi; double flops, bytes; double t0_ms, t1_ms; };   // t0 / t1: against the process epoch (pc_profile_set_epoch)
     std::vector<ProfRec> prof_rec;
     // slice-chain lanes: one pair of non-blocking streams per sub-batch
     struct Lane { hipStream_t sA = nullptr, sB = nullptr; hipEvent_t eA = nullptr, eB = nullptr, eDone = nullptr; };
@@ -160,11 +164,6 @@ int launch_conv(const pc_conv_params& q_in, hipStream_t st)
     q.rowtab_cache = g_rowtabs;
     pc_codec* c = g_prof;
     if (!c) return pc_conv_launch(q, st);
-    if (c->ev_used + 2 > c->ev.size()) {
-        const size_t old = c->ev.size();
-        c->ev.resize(old + 512);
-        for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(hipEventCreate(&c->ev[i]));
-    }
     long taps = 0;
     for (int ph = 0; ph < q.nphase; ++ph) taps += q.ntap[ph];
     const double ng = q.ngroup == 2 ? 2.0 : 1.0;
@@ -177,12 +176,22 @@ int launch_conv(const pc_conv_params& q_in, hipStream_t st)
     by += ng * 4.0 * (double)q.nphase * q.M * q.Cout;
     if (q.aux0 && q.epi != PC_EPI_NONE && q.epi != PC_EPI_GELU && q.epi != PC_EPI_CLAMP01) by += 4.0 * (double)q.nphase * q.M * q.Cout;
     if (q.aux1 && (q.epi == PC_EPI_GATE || q.epi == PC_EPI_LRP_ADD)) by += 4.0 * (double)q.nphase * q.M * q.Cout;
-    c->prof_flops += fl;
-    c->prof_bytes += by;
-    c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl, by});
-    HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
+    hipEvent_t e0, e1;
+    {
+        std::lock_guard<std::mutex> lk(c->prof_mu);                      // (the object's chains may launch from two host threads)
+        if (c->ev_used + 2 > c->ev.size()) {
+            const size_t old = c->ev.size();
+            c->ev.resize(old + 512);
+            for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(hipEventCreate(&c->ev[i]));
+        }
+        c->prof_flops += fl;
+        c->prof_bytes += by;
+        c->prof_rec.push_back({q.M, q.Cout, (int)(taps * q.Cin / q.nphase), q.nphase, q.epi, fl, by, 0.0, 0.0});
+        e0 = c->ev[c->ev_used++]; e1 = c->ev[c->ev_used++];
+    }
+    HIPCHK(hipEventRecord(e0, st));
     const int r = pc_conv_launch(q, st);
-    HIPCHK(hipEventRecord(c->ev[c->ev_used++], st));
+    HIPCHK(hipEventRecord(e1, st));
     return r;
 }
 
@@ -653,9 +662,9 @@ int hyper(pc_codec* c, hipStream_t st, const float* z_hat, int B, int zh, int zw
     // (PC_HYPER_PARALLEL=1).  That was worth 1 % in round 1; with the encoder / decoder objects side by side and the chains pipelined it costs
     // 3 % of the overlapped bench and 2-5 % of the sequential one (profiles/r03_t_hyper_parallel_ab.log): four more streams' launches in a
     // chip that is already shared by four chains.  Default off since round 3.
-    static const bool par = [] { const char* v = std::getenv("PC_HYPER_PARALLEL"); return v && std::atoi(v) != 0; }();
+    static const bool par = pc_tune("PC_HYPER_PARALLEL", 0) != 0;
     const int n = quality != 0 ? 4 : 2;
-    if (!par || c->profile) {
+    if (!par || c->serial_profile() || c->opt_serial) {
         PCCHK(hs(c, st, c->hss[0], z_hat, B, zh, zw, ls, MLAT));
         PCCHK(hs(c, st, c->hms[0], z_hat, B, zh, zw, lm, MLAT));
         if (quality != 0) {                       // CHProg_cnn.py:708-715
@@ -890,6 +899,21 @@ extern "C" int pc_codec_set_tables(pc_codec* c, int which, const int32_t* cdf, i
 }
 
 extern "C" int pc_codec_set_threads(pc_codec* c, int n) { if (!c) return PC_ERR_ARG; c->n_threads = n; return PC_OK; }
+
+// The object's schedule options (the product's replacement for the tuning builds' environment switches; results never depend on them:
+// tests/test_gpu_codec.py::test_schedule_options_do_not_change_results).
+extern "C" int pc_codec_set_option(pc_codec* c, const char* name, int value)
+{
+    if (!c || !name || value < 0) return PC_ERR_ARG;
+    const std::string n(name);
+    if (n == "serial_schedule") c->opt_serial = value ? 1 : 0;
+    else if (n == "lanes_enc") { if (value > 8) return PC_ERR_ARG; c->opt_lanes_enc = value; }
+    else if (n == "lanes_dec") { if (value > 8) return PC_ERR_ARG; c->opt_lanes_dec = value; }
+    else if (n == "host_threads") c->n_threads = value;
+    else if (n == "profile_in_schedule") c->profile_in_schedule = value != 0;
+    else return PC_ERR_ARG;
+    return PC_OK;
+}
 
 extern "C" int pc_codec_finalize(pc_codec* c)
 {
@@ -1134,13 +1158,14 @@ int ensure_lanes(pc_codec* c, int n)
 
 int lane_count(const pc_codec* c, int B, bool decode)
 {
-    static const int env = [] { const char* v = std::getenv("PC_LANES"); return v ? std::atoi(v) : 0; }();
-    static const int env_e = [] { const char* v = std::getenv("PC_LANES_ENC"); return v ? std::atoi(v) : 0; }();
-    static const int env_d = [] { const char* v = std::getenv("PC_LANES_DEC"); return v ? std::atoi(v) : 0; }();
+    static const int env = (int)pc_tune("PC_LANES", 0);
+    static const int env_e = (int)pc_tune("PC_LANES_ENC", 0);
+    static const int env_d = (int)pc_tune("PC_LANES_DEC", 0);
     // Config 2, round-1 final kernels (enc / dec ms per batch): lanes 1/1 35.9 / 36.4, 1/2 35.7 / 35.2, 2/2 37.1 / 36.0 -- the
     // encoder's GEMMs fill the chip best undivided; in the decoder a second lane hides the other lane's host rANS round trips
     int n = decode ? (env_d > 0 ? env_d : (env > 0 ? env : PC_DEFAULT_LANES_DEC)) : (env_e > 0 ? env_e : (env > 0 ? env : PC_DEFAULT_LANES_ENC));
-    if (c->profile) n = 1;
+    if (decode ? c->opt_lanes_dec > 0 : c->opt_lanes_enc > 0) n = decode ? c->opt_lanes_dec : c->opt_lanes_enc;      // pc_codec_set_option
+    if (c->serial_profile() || c->opt_serial) n = 1;
     return std::max(1, std::min(n, std::min(B, 8)));
 }
 
@@ -1267,7 +1292,7 @@ int chain_params(const ChainCtx& k, int step, int b0, int nb, hipStream_t sA, hi
     float* yb = img(k.yb, b0, pi * D0); float* ye = img(k.ye, b0, pi * D0);
     float* mu_i = k.mu + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
     float* sc_i = k.scale + (size_t)step * k.M * SLICE + (size_t)b0 * pi * SLICE;
-    static const bool grouped = [] { const char* v = std::getenv("PC_GROUPED"); return !v || std::atoi(v) != 0; }();
+    static const bool grouped = pc_tune("PC_GROUPED", 1) != 0;
     const std::string tm = "s5m" + tag, ts = "s5s" + tag;
     if (grouped) {   // one grouped launch per layer: mean (z = 0) and scale (z = 1)
         if (step < NS0) {
@@ -1372,6 +1397,7 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
     pc_codec* c = k.c;
     HIPCHK(hipSetDevice(c->device));
     g_rowtabs = c->rowtabs;                                                             // (this may be a lane's own host thread)
+    g_prof = c->profile ? c : nullptr;
     const size_t pi = (size_t)k.HW, per = (size_t)SLICE * k.HW;
     int32_t* h_idx = c->h_idx + k.h_off + (size_t)b0 * per;
     int32_t* h_sym = c->h_sym + k.h_off + (size_t)b0 * per;
@@ -1390,7 +1416,7 @@ int decode_lane(const ChainCtx& k, int b0, int nb, hipStream_t sA, hipStream_t s
                                 c->scale_table, c->n_table, c->scale_bound, k.idx + so, nullptr, sA,
                                 (e && k.cust_map) ? k.cust_map + ((size_t)b0 * D0 + (size_t)SLICE * i) * pi : nullptr, (int64_t)D0 * (int64_t)pi,
                                 k.idx8 + so));
-        static const bool slow_dec = [] { const char* v = std::getenv("PC_DEC_FAST"); return v && std::atoi(v) == 0; }();   // A/B switch
+        static const bool slow_dec = pc_tune("PC_DEC_FAST", 1) == 0;   // A/B switch
         uint8_t* h_idx8 = reinterpret_cast<uint8_t*>(h_idx);
         if (slow_dec) HIPCHK(hipMemcpyAsync(h_idx, k.idx + so, per * nb * 4, hipMemcpyDeviceToHost, sA));
         else HIPCHK(hipMemcpyAsync(h_idx8, k.idx8 + so, per * nb, hipMemcpyDeviceToHost, sA));
@@ -1423,8 +1449,8 @@ int run_chain(const ChainCtx& k, hipStream_t st, bool decode, const uint8_t* con
     pc_codec* c = k.c;
     const int nl = lane_count(c, k.B, decode);
     if (nl == 1) {   // sequential on the caller's stream (also the profiling configuration)
-        static const bool two = [] { const char* v = std::getenv("PC_DUAL_STREAM"); return !v || std::atoi(v) != 0; }();
-        if (!two || c->profile) {
+        static const bool two = pc_tune("PC_DUAL_STREAM", 1) != 0;
+        if (!two || c->serial_profile() || c->opt_serial) {
             return decode ? decode_lane(k, 0, k.B, st, st, nullptr, nullptr, "", y_strings, y_lens, c->n_threads == 1 ? 1 : 0)
                           : encode_lane(k, 0, k.B, st, st, nullptr, nullptr, "");
         }
@@ -1507,8 +1533,8 @@ int encode_streams(pc_codec* c, const int32_t* hs, const int32_t* hi, int first_
 // the decoder one chain's host rANS round trip hides behind the other chain's kernels -- without halving M as batch lanes do.
 bool pipeline_enabled(const pc_codec* c)
 {
-    static const bool on = [] { const char* v = std::getenv("PC_PIPELINE"); return !v || std::atoi(v) != 0; }();
-    return on && !c->profile;
+    static const bool on = pc_tune("PC_PIPELINE", 1) != 0;
+    return on && !c->serial_profile() && !c->opt_serial;
 }
 
 int ensure_pipeline(pc_codec* c, size_t M)
@@ -1624,7 +1650,7 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     // Default OFF since round 3 (PC_NO_STREAMED_ENCODE=0 switches it on): the per-slice copies and events of the side stream cost the
     // overlapped bench 3.4 % (46.7 -> 48.2 MP/s) and buy a sequential caller 0.6 ms of host coding per call -- nothing measurable
     // (profiles/r03_t_streamed_encode_ab.log)
-    static const bool no_stream = [] { const char* v = std::getenv("PC_NO_STREAMED_ENCODE"); return !v || std::atoi(v) != 0; }();
+    static const bool no_stream = pc_tune("PC_NO_STREAMED_ENCODE", 1) != 0;
     const bool can_stream = !no_stream && lane_count(c, B, false) == 1;
     if (can_stream && !c->copy_stream) {
         HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
@@ -1945,7 +1971,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     c->t_host_decode_ms = 0.0;
     int first_enh = -1;
     for (int l = 0; l < n_levels && first_enh < 0; ++l) if (qualities[l] != 0) first_enh = l;
-    static const bool pipe_dec = [] { const char* v = std::getenv("PC_PIPELINE_DEC"); return !v || std::atoi(v) != 0; }();
+    static const bool pipe_dec = pc_tune("PC_PIPELINE_DEC", 1) != 0;
     const bool piped = pipeline_enabled(c) && pipe_dec && first_enh >= 0;
     if (piped) {
         // base chain on `st` (own host thread) || enhancement chain of the first coded level on pipe_stream (this thread), one slice
@@ -2075,30 +2101,64 @@ extern "C" int pc_codec_host_stats(const pc_codec* c, double* out, int n)
     return PC_OK;
 }
 
+// One epoch event per device: what the in-schedule profile of several codec objects (an encoder and a decoder side by side) measures its
+// launch intervals against, so that they can be merged into one timeline.
+static std::mutex g_epoch_mu;
+static hipEvent_t g_epoch[16] = {};
+extern "C" int pc_profile_set_epoch(int device)
+{
+    if (device < 0 || device >= 16) return PC_ERR_ARG;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_epoch_mu);
+    if (!g_epoch[device]) HIPCHK(hipEventCreate(&g_epoch[device]));
+    HIPCHK(hipEventRecord(g_epoch[device], nullptr));
+    HIPCHK(hipEventSynchronize(g_epoch[device]));
+    return PC_OK;
+}
+
 extern "C" int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* total_ms, double* total_flops)
 {
     if (!c || !n_launches || !total_ms || !total_flops) return PC_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipDeviceSynchronize());
+    hipEvent_t epoch = nullptr;
+    { std::lock_guard<std::mutex> lk(g_epoch_mu); if (c->device < 16) epoch = g_epoch[c->device]; }
     double ms = 0.0;
     for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
         float t = 0.0f;
         HIPCHK(hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
         ms += t;
+        if (i / 2 < c->prof_rec.size()) {
+            float s0 = 0.0f;
+            if (epoch && hipEventElapsedTime(&s0, epoch, c->ev[i]) != hipSuccess) { (void)hipGetLastError(); s0 = 0.0f; }
+            c->prof_rec[i / 2].t0_ms = s0;
+            c->prof_rec[i / 2].t1_ms = (double)s0 + t;
+        }
     }
     if (const char* path = std::getenv("PC_PROFILE_CSV")) {      // per-launch shapes and times, for tuning
         if (FILE* f = std::fopen(path, "w")) {
             std::fprintf(f, "i,M,N,K,nphase,epi,gflop,us,tflops,alg_mbytes\n");
-            for (size_t i = 0; i + 1 < c->ev_used && i / 2 < c->prof_rec.size(); i += 2) {
-                float t = 0.0f;
-                (void)hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]);
-                const auto& r = c->prof_rec[i / 2];
-                std::fprintf(f, "%zu,%d,%d,%d,%d,%d,%.3f,%.1f,%.2f,%.3f\n", i / 2, r.M, r.N, r.K, r.nphase, r.epi, r.flops / 1e9, t * 1e3, r.flops / (t * 1e-3) / 1e12, r.bytes / 1e6);
+            for (size_t i = 0; i < c->prof_rec.size(); ++i) {
+                const auto& r = c->prof_rec[i];
+                const double t = r.t1_ms - r.t0_ms;
+                std::fprintf(f, "%zu,%d,%d,%d,%d,%d,%.3f,%.1f,%.2f,%.3f\n", i, r.M, r.N, r.K, r.nphase, r.epi, r.flops / 1e9, t * 1e3, r.flops / (t * 1e-3) / 1e12, r.bytes / 1e6);
             }
             std::fclose(f);
         }
     }
     *n_launches = (int64_t)(c->ev_used / 2); *total_ms = ms; *total_flops = c->prof_flops;
     c->profile = false; c->ev_used = 0; g_prof = nullptr;
+    return PC_OK;
+}
+
+// the launch intervals of the profile that pc_codec_profile_end closed: start / end in ms against the device's epoch, FLOPs per launch
+extern "C" int pc_codec_profile_intervals(const pc_codec* c, double* t0_ms, double* t1_ms, double* flops, size_t cap, size_t* n)
+{
+    if (!c || !n) return PC_ERR_ARG;
+    *n = c->prof_rec.size();
+    if (!t0_ms && !t1_ms && !flops) return PC_OK;                 // size query
+    if (!t0_ms || !t1_ms || !flops || cap < c->prof_rec.size()) return PC_ERR_BUFFER;
+    for (size_t i = 0; i < c->prof_rec.size(); ++i) { t0_ms[i] = c->prof_rec[i].t0_ms; t1_ms[i] = c->prof_rec[i].t1_ms; flops[i] = c->prof_rec[i].flops; }
     return PC_OK;
 }

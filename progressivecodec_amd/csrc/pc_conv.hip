@@ -1139,11 +1139,23 @@ struct pc_rowtab_cache {
             map.erase(victim);
         }
     }
+    // Never called with `mu` held.  A table belongs to the device in its key (the process-wide default cache serves every device): that
+    // device is drained -- a launch already enqueued there may still read the table -- before the table is freed.
     static void free_victims(std::vector<Entry>& victims)
     {
         if (victims.empty()) return;
-        (void)hipDeviceSynchronize();
-        for (auto& v : victims) { (void)hipFree(v.tab); (void)hipEventDestroy(v.ready); }
+        int cur = 0, drained = -1;
+        (void)hipGetDevice(&cur);
+        for (auto& v : victims) {
+            if (v.key.dev != drained) {
+                (void)hipSetDevice(v.key.dev);
+                (void)hipDeviceSynchronize();
+                drained = v.key.dev;
+            }
+            (void)hipFree(v.tab);
+            (void)hipEventDestroy(v.ready);
+        }
+        (void)hipSetDevice(cur);
         victims.clear();
     }
     void unpin(const int* tab)
@@ -1242,19 +1254,21 @@ const int* conv_rowtab(const pc_conv_params& p, hipStream_t stream)
         hipLaunchKernelGGL(conv_rowtab_kernel, dim3(std::min(2048, (p.M + 255) / 256)), dim3(256), 0, stream, p, e.tab);
         if (hipGetLastError() != hipSuccess || hipEventRecord(e.ready, stream) != hipSuccess) { (void)hipFree(e.tab); (void)hipEventDestroy(e.ready); return nullptr; }
     }
-    std::lock_guard<std::mutex> lk(rc->mu);
     const int* other = nullptr;
-    if (lookup(&other) && other) {
-        // another lane built the same geometry while this one was building outside the lock: use (and pin) that table.  Ours may already
-        // be read by nothing (its build kernel is the only work queued on it): drop it after that kernel has run.
-        std::vector<pc_rowtab_cache::Entry> mine{e};
-        pc_rowtab_cache::free_victims(mine);
-        return other;
+    {
+        std::lock_guard<std::mutex> lk(rc->mu);
+        if (!(lookup(&other) && other)) {
+            e.tick = ++rc->tick;
+            rc->bytes += bytes;
+            rc->map.emplace(h, e);
+            return e.tab;
+        }
     }
-    e.tick = ++rc->tick;
-    rc->bytes += bytes;
-    rc->map.emplace(h, e);
-    return e.tab;
+    // another lane built the same geometry while this one was building outside the lock: use (and pin) that table.  Ours is read by
+    // nothing but its own build kernel: dropped after that kernel has run -- the device drain happens here, with the lock released.
+    std::vector<pc_rowtab_cache::Entry> mine{e};
+    pc_rowtab_cache::free_victims(mine);
+    return other;
 }
 
 void conv_rowtab_unpin(const pc_conv_params& p)
@@ -1328,20 +1342,20 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
     // on the device drain in front of an eviction's hipFree protects it) or on any early error return
     struct Unpin { const pc_conv_params& q; ~Unpin() { conv_rowtab_unpin(q); } } unpin_guard{p};
     if (p.nphase < 1 || p.nphase > 4 || p.M <= 0 || p.Cout <= 0 || p.Cin <= 0) return PC_ERR_ARG;
-    static const int dbg_env = [] { const char* v = std::getenv("PC_CONV_DBG"); return v ? std::atoi(v) : 0; }();
+    static const int dbg_env = (int)pc_tune("PC_CONV_DBG", 0);
     if (dbg_env) p.dbg = dbg_env;
     {   // row tables only pay for layers with several taps (1x1 layers: one tap, always valid)
         int tmax = 0;
         for (int ph = 0; ph < p.nphase; ++ph) tmax = std::max(tmax, p.ntap[ph]);
-        static const bool no_tab = [] { const char* v = std::getenv("PC_CONV_NO_ROWTAB"); return v && std::atoi(v) != 0; }();
+        static const bool no_tab = pc_tune("PC_CONV_NO_ROWTAB", 0) != 0;
         // Padding taps (PC_CONV_ROWPERM, default on): on small images a 3x3 window multiplies zero padding for 8 % (16x16), 16 % (8x8),
         // 30 % (4x4) of its MACs.  A tile of consecutive pixels always mixes border and interior rows; with the rows grouped by
         // tap-validity pattern a border tile skips its padding taps as whole runs.  A chain never holds -0 (it starts at +0, exact
         // cancellation rounds to +0), so dropping fmaf(0, w, acc) terms keeps the bits.  Stride 1, "same" output grid, one phase,
         // unified kernel, dense NHWC output, 32-bit piece offsets.
-        static const bool perm_on = [] { const char* v = std::getenv("PC_CONV_ROWPERM"); return !v || std::atoi(v) != 0; }();
-        static const bool uni_on = [] { const char* v = std::getenv("PC_CONV_KERN"); return !v || std::atoi(v) == 1; }();
-        static const long perm_min_blocks = [] { const char* v = std::getenv("PC_CONV_ROWPERM_MIN"); return v ? std::atol(v) : 256L; }();
+        static const bool perm_on = pc_tune("PC_CONV_ROWPERM", 1) != 0;
+        static const bool uni_on = pc_tune("PC_CONV_KERN", 1) == 1;
+        static const long perm_min_blocks = pc_tune("PC_CONV_ROWPERM_MIN", 256L);
         int maxld = 0;
         for (int sg = 0; sg < p.nseg; ++sg) maxld = std::max(maxld, p.seg[sg].ld);
         maxld = std::max(maxld, std::max(p.ld0, p.ld1));
@@ -1355,7 +1369,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         p.rowtab = (p.wlayout == 1 && tmax > 1 && !no_tab) ? conv_rowtab(p, stream) : nullptr;
         if (!p.rowtab) p.rowperm = 0;
     }
-    static const bool group_xcd_on = [] { const char* v = std::getenv("PC_CONV_GROUP_XCD"); return !v || std::atoi(v) != 0; }();
+    static const bool group_xcd_on = pc_tune("PC_CONV_GROUP_XCD", 1) != 0;
     p.group_xcd = (group_xcd_on && p.ngroup == 2 && p.wlayout == 1) ? 1 : 0;
     p.ident_rows = p.nphase == 1 && p.ntap[0] == 1 && p.dy[0][0] == 0 && p.dx[0][0] == 0 && p.stride == 1 &&
                                                 p.Ho == p.H && p.Wo == p.W;
@@ -1389,8 +1403,8 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         // (two chunks in flight) wins or ties on every layer shape of the codec, small and large grids alike -- 64-channel
         // chunks, 2 or 4 stages and the 32x64 / 64x32 / 32x32 block tiles (WM, WN < 2) were all slower or equal.  The other
         // instantiations stay reachable for tuning through PC_CONV_BK / PC_CONV_S.
-        static const int bk_env = [] { const char* v = std::getenv("PC_CONV_BK"); return v ? std::atoi(v) : 0; }();
-        static const int s_env = [] { const char* v = std::getenv("PC_CONV_S"); return v ? std::atoi(v) : 0; }();
+        static const int bk_env = (int)pc_tune("PC_CONV_BK", 0);
+        static const int s_env = (int)pc_tune("PC_CONV_S", 0);
         int chunks = 0;                                    // K-loop length of the longest phase, in 32-channel chunks
         for (int ph = 0; ph < p.nphase; ++ph) {
             int c = 0;
@@ -1400,9 +1414,9 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         const int bk = bk_env ? bk_env : 32;
         const int S = s_env ? s_env : (chunks <= 8 ? 2 : 3);   // 1x1 layers with K <= 256: two stages (nothing to keep in flight)
         // kernel family: 0 = wave-specialised (round 1), 1 = unified (every wave loads and multiplies)
-        static const int kern_env = [] { const char* v = std::getenv("PC_CONV_KERN"); return v ? std::atoi(v) : 1; }();
-        static const int tm_env = [] { const char* v = std::getenv("PC_CONV_TM"); return v ? std::atoi(v) : 0; }();
-        static const int tn_env = [] { const char* v = std::getenv("PC_CONV_TN"); return v ? std::atoi(v) : 0; }();
+        static const int kern_env = (int)pc_tune("PC_CONV_KERN", 1);
+        static const int tm_env = (int)pc_tune("PC_CONV_TM", 0);
+        static const int tn_env = (int)pc_tune("PC_CONV_TN", 0);
         e = hipErrorInvalidValue;
         if (kern_env == 1) {
             // Kernel choice (PC_CONV_POLICY; tools/conv_tune.py, bench A/Bs: profiles/r02_l_*, r02_n_*, r02_o_*).  3 (default): K-chunk 16,
@@ -1412,9 +1426,9 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
             // except 128x64 two-accumulator blocks on the large layers.  0: the first half of round 2 (K-chunk 32; 128x64 blocks with two
             // stages once there are >= 1536 of the 64x64 blocks).  All of them produce identical bits.
             const long nb64 = (long)((p.M + 63) / 64) * ((p.Cout + 63) / 64) * (p.ngroup == 2 ? 2 : p.nphase);
-            static const int policy = [] { const char* v = std::getenv("PC_CONV_POLICY"); return v ? std::atoi(v) : 3; }();
-            static const long small_thr = [] { const char* v = std::getenv("PC_CONV_SMALL_THR"); return v ? std::atol(v) : 256L; }();
-            static const long tm_thr = [] { const char* v = std::getenv("PC_CONV_TM_THR"); return v ? std::atol(v) : 1536L; }();
+            static const int policy = (int)pc_tune("PC_CONV_POLICY", 3);
+            static const long small_thr = pc_tune("PC_CONV_SMALL_THR", 256L);
+            static const long tm_thr = pc_tune("PC_CONV_TM_THR", 1536L);
             int tm = tm_env ? tm_env : (nb64 >= tm_thr ? 2 : 1), tn = tn_env ? tn_env : 1;
             const int Su = s_env ? s_env : ((chunks <= 8 || tm * tn > 1) ? 2 : 3);
             const int ab = (p.dbg & 64) ? 0 : (p.dbg & 15);                   // ablation builds of the 64x64 three-stage instantiation

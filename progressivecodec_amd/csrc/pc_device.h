@@ -7,6 +7,18 @@
 
 #include "../../include/pcodec.h"
 
+// Tuning scaffolding.  The A/B builds of the profiling rounds (`make tuning` -> libpcodec_tuning.so, -DPC_TUNING; tools/env_matrix.sh,
+// tools/gpu_ab.sh select it with PC_LIB) read their switches from the environment; the PRODUCT library reads none of them -- pc_tune()
+// is the compiled-in default there.  What the product does read: PC_HOST_THREADS / PC_HOST_NO_PIN (host entropy-coding pool),
+// LOCAL_RANK / LOCAL_WORLD_SIZE (the launcher's), PC_TIMING, PC_PROFILE_CSV (diagnostics); the schedule is set per object with
+// pc_codec_set_option (include/pcodec.h).
+#ifdef PC_TUNING
+#include <cstdlib>
+static inline long pc_tune(const char* name, long dflt) { const char* v = std::getenv(name); return v ? std::atol(v) : dflt; }
+#else
+static inline constexpr long pc_tune(const char*, long dflt) { return dflt; }
+#endif
+
 #define PC_MAX_SEG 8
 #define PC_MAX_TAP 25
 

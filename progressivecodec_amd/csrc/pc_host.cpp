@@ -80,11 +80,15 @@ extern "C" int pc_rans_encode_with_indexes(const int32_t* symbols, const int32_t
         if (len < 2 || len > cdf_stride) return PC_ERR_CDF;
         const int32_t* cdf = cdfs + (size_t)ci * cdf_stride;
         const int32_t max_value = len - 2;                                            // :115
-        int32_t value = symbols[ii] - offsets[ci];                                    // :119
+        // (all of this in 64 bits: the reference's int32 arithmetic overflows -- undefined behaviour -- for symbols near INT32_MIN/MAX,
+        // rans_interface.cpp:119-133; a symbol whose escape code does not fit the 8 nibbles the decoder reads back is refused instead)
+        const int64_t v64 = (int64_t)symbols[ii] - (int64_t)offsets[ci];              // :119
+        int32_t value = 0;
         uint32_t raw = 0;
         bool escaped = false;
-        if (value < 0) { raw = (uint32_t)(-2 * (int64_t)value - 1); value = max_value; escaped = true; }
-        else if (value >= max_value) { raw = (uint32_t)(2 * ((int64_t)value - max_value)); value = max_value; escaped = true; }
+        if (v64 < 0) { const int64_t r = -2 * v64 - 1; if (r > 0xffffffffll) return PC_ERR_ARG; raw = (uint32_t)r; value = max_value; escaped = true; }
+        else if (v64 >= max_value) { const int64_t r = 2 * (v64 - max_value); if (r > 0xffffffffll) return PC_ERR_ARG; raw = (uint32_t)r; value = max_value; escaped = true; }
+        else value = (int32_t)v64;
         if (escaped) {
             // forward order is: symbol, count nibbles (15,15,...,rest), value nibbles (LSB first)   :138-162
             // -> encode in exact reverse
@@ -95,8 +99,8 @@ extern "C" int pc_rans_encode_with_indexes(const int32_t* symbols, const int32_t
             enc_put_bits(x, wr, (uint32_t)rest);
             for (int32_t j = 0; j < full; ++j) enc_put_bits(x, wr, kBypassMax);
         }
-        const uint32_t start = (uint32_t)cdf[value], freq = (uint32_t)(cdf[value + 1] - cdf[value]);
-        if (freq == 0 || freq > 65536u) return PC_ERR_CDF;
+        const uint32_t start = (uint32_t)cdf[value], freq = (uint32_t)cdf[value + 1] - (uint32_t)cdf[value];
+        if (freq == 0 || start > 65535u || freq > 65536u - start) return PC_ERR_CDF;     // (a row that is not an increasing CDF up to 2^16)
         enc_put(x, wr, start, freq);
     }
     wr.put((uint32_t)(x >> 32));                                                      // Rans64EncFlush, rans64.h:96-103
@@ -135,21 +139,22 @@ int rans_decode_core(const uint8_t* encoded, size_t encoded_len, uint64_t& x, si
         int32_t lo = 0, hi = len - 1;
         while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if ((uint32_t)cdf[mid] <= cf) lo = mid; else hi = mid; }
         const int32_t s = lo;
-        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)(cdf[s + 1] - cdf[s]);
+        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)cdf[s + 1] - start;
+        if (start > cf || freq == 0 || freq > 65536u) return PC_ERR_CDF;               // (the row is not an increasing CDF: the reference asserts, :48-57)
         x = (uint64_t)freq * (x >> kPrecision) + (x & 0xFFFFu) - start;               // Rans64DecAdvance, rans64.h:126-142
         renorm();
-        int32_t value = s;
-        if (value == max_value) {                                                      // :247-269
+        uint32_t value = (uint32_t)s;                                                   // (unsigned: a corrupt stream may carry any 32-bit escape code)
+        if (s == max_value) {                                                          // :247-269
             int32_t val = get_bits();
-            int32_t n_bypass = val;
+            int64_t n_bypass = val;
             while (val == kBypassMax) { val = get_bits(); n_bypass += val; if (trunc) return PC_ERR_TRUNCATED; }
-            int32_t raw = 0;
-            for (int32_t j = 0; j < n_bypass; ++j) { val = get_bits(); if (j < 8) raw |= val << (j * kBypassBits); }
+            uint32_t raw = 0;
+            for (int64_t j = 0; j < n_bypass; ++j) { val = get_bits(); if (j < 8) raw |= (uint32_t)val << (j * kBypassBits); if (trunc) return PC_ERR_TRUNCATED; }
             value = raw >> 1;
-            if (raw & 1) value = -value - 1; else value += max_value;
+            if (raw & 1) value = 0u - value - 1u; else value += (uint32_t)max_value;
         }
         if (trunc) return PC_ERR_TRUNCATED;
-        out[i] = value + offsets[ci];
+        out[i] = (int32_t)(value + (uint32_t)offsets[ci]);
     }
     return PC_OK;
 }
@@ -197,7 +202,7 @@ extern "C" int pc_pmf_to_quantized_cdf(const float* pmf, int n, int precision, u
     cdf[0] = 0;
     for (int i = 0; i < n; ++i) {
         const float p = pmf[i];
-        if (!(p >= 0.0f) || !std::isfinite(p)) return PC_ERR_CDF;
+        if (!(p >= 0.0f) || !std::isfinite(p) || p > 65535.0f) return PC_ERR_CDF;      // (beyond that the float -> uint32 conversion below is undefined)
         cdf[i + 1] = (uint32_t)std::round(p * (float)(1 << precision));               // ops.cpp:20-21
     }
     uint32_t total = 0;
@@ -385,7 +390,12 @@ ThreadPool& default_pool()
 
 namespace pc {
 
-void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint16_t* lut)
+// Start table of the fast decoder: for row r and the high byte `hi` of the 16-bit cumulative frequency, ONE 64-bit entry holding the
+// largest s (<= len-2) with row[s] <= hi << 8 together with row[s] and row[s+1]:  s | row[s] << 16 | row[s+1] << 32.  A symbol whose
+// interval contains the whole bucket -- the common case on the peaked rows that carry most symbols -- is resolved by that one load;
+// the decoder steps forward through the row only when cf >= row[s+1].  (Round 3 kept s alone and loaded row[s+1], row[s] behind it: two
+// dependent loads on the chain that IS the per-stream decode rate.)
+void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint64_t* lut)
 {
     for (int r = 0; r < n; ++r) {
         const int32_t* row = cdf + (size_t)r * stride;
@@ -393,7 +403,7 @@ void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len,
         for (int hi = 0; hi < 256; ++hi) {
             const int32_t v = hi << 8;
             while (s + 1 < len[r] - 1 && row[s + 1] <= v) ++s;         // largest s <= len-2 with row[s] <= v
-            lut[(size_t)r * 256 + hi] = (uint16_t)s;
+            lut[(size_t)r * 256 + hi] = (uint64_t)(uint16_t)s | ((uint64_t)(uint32_t)row[s] << 16) | ((uint64_t)(uint32_t)row[s + 1] << 32);
         }
     }
 }
@@ -420,22 +430,26 @@ struct DecState {
         const int32_t len = t.len[ci];
         const int32_t* cdf = t.cdf + (size_t)ci * t.stride;
         const uint32_t cf = (uint32_t)(x & 0xFFFFu);
-        int32_t s = t.lut[(size_t)ci * 256 + (cf >> 8)];
-        while ((uint32_t)cdf[s + 1] <= cf) ++s;                           // cdf[len-1] = 65536 > cf: stops at s <= len-2
-        const uint32_t start = (uint32_t)cdf[s], freq = (uint32_t)cdf[s + 1] - start;
-        x = (uint64_t)freq * (x >> kPrecision) + cf - start;
-        renorm();
-        int32_t value = s;
-        if (s == len - 2) {                                               // bypass, rans_interface.cpp:247-269
-            int32_t val = bits();
-            int32_t nb = val;
-            while (val == kBypassMax && !err) { val = bits(); nb += val; }
-            int32_t raw = 0;
-            for (int32_t j = 0; j < nb && !err; ++j) { val = bits(); if (j < 8) raw |= val << (j * kBypassBits); }
-            value = raw >> 1;
-            if (raw & 1) value = -value - 1; else value += len - 2;
+        const uint64_t e = t.lut[(size_t)ci * 256 + (cf >> 8)];
+        int32_t s = (int32_t)(e & 0xffffu);
+        uint32_t start = (uint32_t)(e >> 16) & 0xffffu, next = (uint32_t)(e >> 32);
+        if (__builtin_expect(next <= cf, 0)) {                            // the bucket holds a boundary below cf: walk the row
+            do { ++s; } while ((uint32_t)cdf[s + 1] <= cf);               // cdf[len-1] = 65536 > cf: stops at s <= len-2
+            start = (uint32_t)cdf[s]; next = (uint32_t)cdf[s + 1];
         }
-        return value + t.off[ci];
+        x = (uint64_t)(next - start) * (x >> kPrecision) + cf - start;
+        renorm();
+        uint32_t value = (uint32_t)s;
+        if (__builtin_expect(s == len - 2, 0)) {                          // bypass, rans_interface.cpp:247-269
+            int32_t val = bits();
+            int64_t nb = val;
+            while (val == kBypassMax && !err) { val = bits(); nb += val; }
+            uint32_t raw = 0;
+            for (int64_t j = 0; j < nb && !err; ++j) { val = bits(); if (j < 8) raw |= (uint32_t)val << (j * kBypassBits); }
+            value = raw >> 1;
+            if (raw & 1) value = 0u - value - 1u; else value += (uint32_t)(len - 2);
+        }
+        return (int32_t)(value + (uint32_t)t.off[ci]);
     }
 };
 }  // namespace
@@ -444,6 +458,7 @@ int rans_decode_u8_batch(const uint8_t* const* encoded, const size_t* encoded_le
                          const DecTables& t, int32_t* out, int n_threads)
 {
     if (!encoded || !encoded_lens || (!indexes && n) || !t.cdf || !t.lut || (!out && n)) return PC_ERR_ARG;
+    for (size_t s = 0; s < n_streams; ++s) if (!encoded[s] && encoded_lens[s]) return PC_ERR_ARG;
     std::atomic<int> rc{PC_OK};
     const size_t n_pairs = (n_streams + 1) / 2;
     auto job = [&](size_t pr) {
@@ -475,7 +490,7 @@ extern "C" int pc_rans_encode_batch(const int32_t* symbols, const int32_t* index
                                     const int32_t* cdf_sizes, const int32_t* offsets,
                                     uint8_t* out, size_t out_stride, size_t* out_lens, int n_threads)
 {
-    if (!out || !out_lens || (out_stride & 3)) return PC_ERR_ARG;
+    if (!out || !out_lens || (out_stride & 3) || ((!symbols || !indexes) && n && n_streams)) return PC_ERR_ARG;
     std::atomic<int> rc{PC_OK};
     auto job = [&](size_t s) {
         const int r = pc_rans_encode_with_indexes(symbols + s * n, indexes + s * n, n, cdfs, n_cdf, cdf_stride, cdf_sizes,
@@ -493,7 +508,8 @@ extern "C" int pc_rans_decode_batch(const uint8_t* const* encoded, const size_t*
                                     const int32_t* cdf_sizes, const int32_t* offsets,
                                     int32_t* out, int n_threads)
 {
-    if (!encoded || !encoded_lens) return PC_ERR_ARG;
+    if (!encoded || !encoded_lens || ((!indexes || !out) && n && n_streams)) return PC_ERR_ARG;
+    for (size_t s = 0; s < n_streams; ++s) if (!encoded[s]) return PC_ERR_ARG;
     std::atomic<int> rc{PC_OK};
     auto job = [&](size_t s) {
         const int r = pc_rans_decode_with_indexes(encoded[s], encoded_lens[s], indexes + s * n, n, cdfs, n_cdf, cdf_stride,
@@ -517,7 +533,7 @@ extern "C" int pc_rans_decode_batch_u8(const uint8_t* const* encoded, const size
         if (cdf_sizes[i] < 2 || cdf_sizes[i] > cdf_stride || row[0] != 0 || row[cdf_sizes[i] - 1] != (1 << 16)) return PC_ERR_CDF;
         for (int j = 0; j + 1 < cdf_sizes[i]; ++j) if (row[j + 1] <= row[j]) return PC_ERR_CDF;
     }
-    std::vector<uint16_t> lut((size_t)n_cdf * 256);
+    std::vector<uint64_t> lut((size_t)n_cdf * 256);
     pc::build_decode_lut(cdfs, n_cdf, cdf_stride, cdf_sizes, lut.data());
     return pc::rans_decode_u8_batch(encoded, encoded_lens, n_streams, indexes, n, pc::DecTables{cdfs, n_cdf, cdf_stride, cdf_sizes, offsets, lut.data()}, out,
                                     n_threads);

@@ -24,9 +24,9 @@ ThreadPool& default_pool();
 // states give the core something to overlap the dependent loads of one with).  Same symbols as pc_rans_decode_with_indexes.
 struct DecTables {
     const int32_t* cdf; int n, stride; const int32_t* len; const int32_t* off;
-    const uint16_t* lut;          // [n][256]: largest s with cdf[s] <= (hi << 8), built by build_decode_lut
+    const uint64_t* lut;          // [n][256]: s | cdf[s] << 16 | cdf[s+1] << 32 for the largest s with cdf[s] <= (hi << 8), built by build_decode_lut
 };
-void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint16_t* lut);
+void build_decode_lut(const int32_t* cdf, int n, int stride, const int32_t* len, uint64_t* lut);
 int rans_decode_u8_batch(const uint8_t* const* encoded, const size_t* encoded_lens, size_t n_streams, const uint8_t* indexes, size_t n,
                          const DecTables& t, int32_t* out, int n_threads);
 }  // namespace pc

@@ -679,7 +679,7 @@ __global__ __launch_bounds__(256) void gc_dequant_vec_kernel(const pc_prep_param
 static inline bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
 static bool prep_vec_ok(const pc_prep_params& p, int mode)   // mode 0 encoder, 1 decoder index, 2 dequantise
 {
-    static const bool off = [] { const char* v = std::getenv("PC_PREP_SCALAR"); return v && std::atoi(v) != 0; }();
+    static const bool off = pc_tune("PC_PREP_SCALAR", 0) != 0;
     if (off || (p.HW & 3) || p.mask_src) return false;
     bool ok = true;
     if (mode != 2) ok = ok && al16(p.scale) && !(p.ld_scale & 3) && al16(p.idx) && al16(p.mask) && (!p.idx8 || !(reinterpret_cast<uintptr_t>(p.idx8) & 3u));
@@ -830,7 +830,7 @@ int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, flo
     if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
     if (sb == 0) sb = (int64_t)HW * ld;
     const int64_t n = (int64_t)HW * C;
-    static const bool single = [] { const char* v = std::getenv("PC_QUANTILE_SINGLE"); return v && std::atoi(v) != 0; }();
+    static const bool single = pc_tune("PC_QUANTILE_SINGLE", 0) != 0;
     if (n <= 1024 * 8) hipLaunchKernelGGL(quantile_thr_kernel<8>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else if (n <= PC_QUANTILE_SMALL_N) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else if (single) hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);

@@ -142,6 +142,9 @@ class ChannelProgresssiveWACNN(_module_base()):
                 self._h = C.c_void_p()
                 check(lib().pc_codec_create(C.byref(self._h), self.device.index or 0), "pc_codec_create")
                 self._finalized = False
+                # the fresh handle holds no tables and the checkpoint's own scale table: forget the old handle's (ADVICE r03 -- update()
+                # would otherwise see them set and skip, leaving the native side without CDFs or with CDFs of another scale table)
+                self._gc = self._eb = self._scale_table = None
         for k, a in (_extra or {}).items():
             a = np.ascontiguousarray(a, np.float32)
             shp = (C.c_int64 * a.ndim)(*a.shape)
@@ -204,6 +207,12 @@ class ChannelProgresssiveWACNN(_module_base()):
             self._set_tables(1, entropy.entropy_bottleneck_tables(self._sd))
             updated = True
         return updated
+
+    def set_option(self, name, value):
+        """pc_codec_set_option: schedule options of this object ("serial_schedule", "lanes_enc", "lanes_dec", "host_threads") -- results never
+        depend on them.  Options belong to the native handle: a reload of a finalised codec (load_state_dict) starts from the defaults."""
+        check(lib().pc_codec_set_option(self._h, name.encode(), int(value)), f"pc_codec_set_option({name})")
+        return self
 
     # ------------------------------------------------------------------ the hot path
     def _stream(self):

@@ -19,6 +19,56 @@ def shard_range(n_images: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < rem else 0)
 
 
+def _visible_list(env):
+    """The device subset the HIP runtime will expose, from the environment a child rank inherits: ROCR_VISIBLE_DEVICES filters first
+    (at the ROCr level), then HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES index into what is left.  Returns the number of entries of the
+    narrowest list, or None when no variable is set.  An empty string hides every device (0)."""
+    n = None
+    for name in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(name)
+        if v is None:
+            continue
+        k = len([t for t in v.split(",") if t.strip() != ""])
+        n = k if n is None else min(n, k)
+    return n
+
+
+def count_gpus_without_hip(env=None, sysfs_root="/sys/class/kfd/kfd/topology/nodes", probe_in_child=True):
+    """Number of GPUs a rank started from this process would see -- WITHOUT initialising HIP / HSA here.  A launcher that goes on to
+    start its ranks (fork + exec) must not have touched the GPU runtime first: torch.cuda.device_count() can fall through to
+    hipGetDeviceCount on ROCm, so the count is taken from the KFD topology in sysfs (a node with simd_count > 0 is a GPU; CPU
+    nodes have 0), narrowed by the *_VISIBLE_DEVICES variables.  Without the sysfs tree (no amdgpu driver: the build container) the
+    count comes from a short-lived child process that exits before any rank is started; with neither, 0."""
+    import glob
+    import os
+    env = os.environ if env is None else env
+    nodes = sorted(glob.glob(os.path.join(sysfs_root, "*", "properties")))
+    n = None
+    if nodes:
+        n = 0
+        for f in nodes:
+            try:
+                props = dict(line.split(None, 1) for line in open(f).read().splitlines() if " " in line)
+            except OSError:                          # a node this cgroup may not read is not a device this process can use
+                continue
+            if int(props.get("simd_count", "0").strip() or 0) > 0:
+                n += 1
+    elif probe_in_child:
+        import subprocess
+        import sys
+        try:
+            r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], env=dict(env), capture_output=True,
+                               text=True, timeout=300)
+            n = int(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+            return n                                 # the child already honoured the *_VISIBLE_DEVICES variables
+        except (OSError, ValueError, subprocess.SubprocessError):
+            n = 0
+    else:
+        n = 0
+    vis = _visible_list(env)
+    return n if vis is None else min(n, vis)
+
+
 def gather_bitstreams(strings: Sequence[Sequence[bytes]], group=None, device=None) -> List[List[bytes]]:
     """All-gather per-slice lists of per-image byte strings from every rank, in rank order.
 

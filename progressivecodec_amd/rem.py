@@ -89,18 +89,24 @@ class PostRateProcessedNetwork(_module_base()):
     def update(self, *a, **kw):
         return self.base_net.update(*a, **kw)
 
-    def _on(self, checkpoint_rep=None):
+    def _on(self, checkpoint_rep, B, h, w):
+        """Switch the refinement on for the next base_net call of a [B, ., 16h, 16w] batch.  The checkpoint pointer is ALWAYS (re)set --
+        NULL without a checkpoint_rep -- so a pointer left behind by a call that failed before the native side consumed it can never
+        reach the next one; its shape is checked against the call's own, as the reference's torch.cat would (CHProgREM.py:773,989):
+        the native nets index it with the call's B and h*w."""
         if self._post is None:
             raise ValueError("load_state_dict(state_dict_base, state_dict_post) first: the REM needs its post_latent weights")
+        rep = None
+        if checkpoint_rep is not None:
+            import torch
+            if checkpoint_rep.dim() != 4 or tuple(checkpoint_rep.shape) != (B, 320, h, w):
+                raise ValueError(f"checkpoint_rep must be [B, 320, H/16, W/16] = {(B, 320, h, w)}, got {tuple(checkpoint_rep.shape)}")
+            rep = checkpoint_rep.to(self.base_net.device, torch.float32).contiguous()
         lv = (C.c_double * self.check_multiple)(*self.check_levels)
         check(lib().pc_codec_set_rem(self.base_net._h, lv, self.check_multiple), "pc_codec_set_rem")
-        if checkpoint_rep is not None:                                      # CHProgREM.py:773,989
-            import torch
-            rep = checkpoint_rep.to(self.base_net.device, torch.float32).contiguous()
-            if rep.dim() != 4 or rep.shape[1] != 320:
-                raise ValueError("checkpoint_rep must be [B, 320, H/16, W/16]")
-            self._rep = rep                                                 # kept alive until the call has consumed it
-            check(lib().pc_codec_set_rem_checkpoint(self.base_net._h, C.c_void_p(rep.data_ptr())), "pc_codec_set_rem_checkpoint")
+        self._rep = rep                                                     # kept alive until the call has consumed it
+        check(lib().pc_codec_set_rem_checkpoint(self.base_net._h, C.c_void_p(rep.data_ptr()) if rep is not None else None),
+              "pc_codec_set_rem_checkpoint")
 
     def extract_chekpoint_representation_from_images(self, x, quality, rc=True):
         """CHProgREM.py:335-373 (name as in the reference): the y_hat a coder of `quality` produced -- with escalation=True, chained
@@ -116,13 +122,17 @@ class PostRateProcessedNetwork(_module_base()):
         return self.compress(x, quality=self.check_levels[2], mask_pol="point-based-std", checkpoint_rep=rep1, real_compress=rc)["y_hat"]
 
     def _off(self):
+        check(lib().pc_codec_set_rem_checkpoint(self.base_net._h, None), "pc_codec_set_rem_checkpoint")
+        self._rep = None
         check(lib().pc_codec_set_rem(self.base_net._h, None, 0), "pc_codec_set_rem")
 
     def compress(self, x, quality=0.0, mask_pol="point-based-std", checkpoint_rep=None, real_compress=True, used_qual=None):
         """CHProgREM.py:673-888 -> {"strings", "shape", "masks", "y_hat"}."""
         if not real_compress:
             raise NotImplementedError("real_compress=False (the training-time quantiser without entropy coding) is out of scope")
-        self._on(checkpoint_rep)
+        if x.dim() != 4:
+            raise ValueError("Invalid `inputs` size. Expected a [B,3,H,W] tensor.")
+        self._on(checkpoint_rep, x.shape[0], x.shape[2] // 16, x.shape[3] // 16)
         try:
             out = self.base_net.compress(x, quality, mask_pol)
             out["y_hat"] = self.base_net.read_latent("yhat_enh" if quality > 0 else "yhat_base", x.shape[0], x.shape[2] // 16, x.shape[3] // 16)
@@ -133,7 +143,9 @@ class PostRateProcessedNetwork(_module_base()):
     def decompress(self, strings, shape, quality, mask_pol=None, checkpoint_rep=None, timing=False, used_qual=None):
         """CHProgREM.py:896-1126 -> {"x_hat", "y_hat", "time"}."""
         import time
-        self._on(checkpoint_rep)
+        if not isinstance(strings, (tuple, list)) or len(strings) != 2:
+            raise ValueError("Invalid `strings` parameter type.")
+        self._on(checkpoint_rep, len(strings[1]), 4 * int(shape[0]), 4 * int(shape[1]))
         try:
             t0 = time.time()
             out = self.base_net.decompress(strings, shape, quality, mask_pol)

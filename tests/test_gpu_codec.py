@@ -998,7 +998,22 @@ def test_config2_b32_vs_reference_golden():
           f"flip-free images {len(cmp_['flip_free_images'])}/32 (max |dPSNR| {worst_ff:.2e} dB, 1e-4 asserted), flipped images: first diverging slice "
           f"histogram {cmp_['first_diverging_slice_histogram']} (max |dPSNR| {worst_fl:.2e} dB); bpp {bpp:.6f} vs {r['bpp']:.6f}, psnr {psnr:.6f} vs {r['psnr']:.6f}")
     assert abs(bpp - r["bpp"]) <= 1e-3 * r["bpp"] and abs(psnr - r["psnr"]) <= 1e-3
-    assert cmp_["z_strings_identical"] >= 28 and len(cmp_["flip_free_images"]) >= 4     # (round 2 saw 30/32 and 11/32 against the CPU port)
+    # floors at the measured values minus a small margin (measured 31 / 32, 10 / 32 flip-free, 31 / 32 within 1e-4 dB) -- the GPU is
+    # deterministic, so a change here is a change of the numeric contract or of the kernels' arithmetic, never noise
+    within = sum(abs(psnr_of(x[b], x_hat[b]) - r["psnr_per_image"][b]) <= NORTH_STAR_PSNR_TOL_DB for b in range(B))
+    assert cmp_["z_strings_identical"] >= 31 and len(cmp_["flip_free_images"]) >= 9 and within >= 28, (cmp_["z_strings_identical"], len(cmp_["flip_free_images"]), within)
+    # root flips: the elements that differ from the REFERENCE's inside each image's first diverging slice (tests/golden/config2_roots.npz,
+    # the reference's own symbol / index planes) -- the float-rounding flips themselves, asserted as a RATE per coded symbol, and equal to
+    # what the contract oracle differs by (the GPU is that oracle bit for bit)
+    import bench
+    per = 32 * (S // 16) ** 2
+    gsym = net.read_tap("sym", np.int32)[: 20 * B * per].reshape(20, B, per)     # planes of the compress() above (decompress leaves them)
+    gidx = net.read_tap("idx", np.int32)[: 20 * B * per].reshape(20, B, per)
+    rf = bench.root_flips_vs_reference(gsym, gidx, cmp_["first_diverging_slice"])
+    print("root flips vs the reference:", {k: v for k, v in rf.items() if k != "per_image_slice_symbols_indexes"})
+    assert rf["source"] and not rf["images_whose_first_slice_moved"]
+    assert (rf["symbols"], rf["indexes"]) == (rf["expected_by_fixture"]["symbols"], rf["expected_by_fixture"]["indexes"])
+    assert rf["rate_per_coded_symbol"] <= 2e-5, rf["rate_per_coded_symbol"]        # ~1e-5 measured: one flip per ~100 000 coded symbols
 
 
 def test_config3_kodak_sized_set_all_13_levels():
@@ -1139,3 +1154,181 @@ def test_harness_batching_same_size_images_gives_the_same_rd_table():
     mp = 24 * 512 * 768 * 13 / 1e6
     print(f"Config 3 (24 images x 13 levels, encode + decode): one image at a time {t1 - t0:.2f} s ({mp / (t1 - t0):.1f} level-MP/s), "
           f"same-size images batched {t2 - t1:.2f} s ({mp / (t2 - t1):.1f} level-MP/s)")
+
+
+# ------------------------------------------------------------------ round 4: the encoder || decoder schedule as a library object
+def test_codec_pipeline_equals_sequential_calls():
+    """progressivecodec_amd.CodecPipeline.code(): the decode of job i beside the encode of job i+1 on the library's own encoder / decoder
+    objects, streams and decoder thread.  Eight different batches (two shapes, three qualities, one multi-level job):
+    every string, mask and reconstruction equals what the same calls give one after the other on one object -- and the pipeline built
+    AROUND an existing model (from_model) gives the same."""
+    from progressivecodec_amd import CodecPipeline
+    from tests.util import synth_sd
+    net = gpu_codec()
+    g = torch.Generator().manual_seed(404)
+    jobs = []
+    for i in range(8):
+        shape = (4, 3, 128, 128) if i % 3 else (2, 3, 64, 192)
+        job = {"x": torch.rand(*shape, generator=g).cuda(), "mask_pol": "point-based-std"}
+        if i == 5:
+            job["qualities"] = [0.0, 0.5, 10.0]
+        else:
+            job["quality"] = [0.5, 0.0, 2.0][i % 3]
+        jobs.append(job)
+    want = []
+    for job in jobs:                                             # the sequential answer, on one plain model object
+        if "qualities" in job:
+            enc = net.compress_levels(job["x"], job["qualities"], mask_pol="point-based-std")
+            dec = net.decompress_levels([d["strings"] for d in enc], enc[0]["shape"], job["qualities"], mask_pol="point-based-std")
+            want.append(([d["strings"] for d in enc], [d["x_hat"].clone() for d in dec], [[m.clone() for m in d["masks"]] for d in enc]))
+        else:
+            enc = net.compress(job["x"], job["quality"], "point-based-std")
+            dec = net.decompress(enc["strings"], enc["shape"], job["quality"], "point-based-std")
+            want.append((enc["strings"], dec["x_hat"].clone(), [m.clone() for m in enc["masks"]]))
+
+    def check(results):
+        assert len(results) == len(jobs)
+        for (job, enc, dec), ref, j0 in zip(results, want, jobs):
+            assert job is j0                                        # in job order
+            if "qualities" in job:
+                assert [d["strings"] for d in enc] == ref[0]
+                assert all(torch.equal(d["x_hat"], r) for d, r in zip(dec, ref[1]))
+                assert all(torch.equal(m, rm) for d, rms in zip(enc, ref[2]) for m, rm in zip(d["masks"], rms))
+            else:
+                assert enc["strings"] == ref[0] and torch.equal(dec["x_hat"], ref[1])
+                assert len(enc["masks"]) == len(ref[2]) and all(torch.equal(m, rm) for m, rm in zip(enc["masks"], ref[2]))
+
+    pipe = CodecPipeline(synth_sd(), device="cuda:0")
+    assert pipe.enc._h.value != pipe.dec._h.value and pipe.hw_queues_ok in (True, False)
+    check(pipe.run(jobs))
+    check(pipe.run(jobs))                                           # the object is reusable
+    check(list(pipe.code_sequential(jobs)))
+    seen = []
+    check(list(pipe.code(iter(jobs), on_encoded=lambda job, enc: seen.append(job))))
+    assert seen == jobs
+    pipe2 = CodecPipeline.from_model(net, queue_depth=1)
+    assert pipe2.enc is net
+    check(pipe2.run(jobs))
+    # a failing job surfaces as its exception on the caller's thread and leaves the pipeline usable
+    bad = [jobs[0], {"x": torch.rand(1, 3, 64, 64).cuda(), "quality": 0.5, "mask_pol": "no-such-policy"}, jobs[1]]
+    with pytest.raises(NotImplementedError):
+        pipe.run(bad)
+    check(pipe.run(jobs))
+    # in-schedule profile: brackets only, same results, intervals on one timeline
+    pr = pipe.profile_conv_in_schedule(jobs)
+    assert pr["jobs"] == len(jobs) and pr["launches"] > 500 and 0 < pr["busy_ms"] <= pr["window_ms"] * 1.001 and pr["sum_ms"] >= pr["busy_ms"] * 0.999
+    assert pr["algorithmic_flops"] > 0
+    check(pipe.run(jobs))
+
+
+def test_harness_overlap_gives_the_same_rd_table():
+    """compress_with_ac(overlap=True): the reference's loop (training/step.py:297-340) through the library's CodecPipeline -- groups of
+    same-size images, the decode of group i beside the encode of group i+1.  Same RD rows as the shared-base loop; and the Config-3 set
+    through it (>= 85 level-MP/s asked, 77 without the overlap)."""
+    import time
+    from progressivecodec_amd.harness import PR_LIST, compress_with_ac, config3_images
+    net = gpu_codec()
+    imgs = [inputs(1, 64, 128, 41), inputs(1, 96, 72, 42, "smooth"), inputs(1, 64, 128, 43, "smooth"), inputs(1, 96, 72, 44), inputs(1, 64, 128, 45)]
+    levels = [PR_LIST[i] for i in (0, 4, 9, 12)]
+    b1, p1, _, rows1 = compress_with_ac(net, imgs, levels, shared_base=True)
+    b2, p2, t2, rows2 = compress_with_ac(net, imgs, levels, overlap=True, group_size=2)
+    assert [r["quality"] for r in rows1] == [r["quality"] for r in rows2]
+    assert [r["bpp"] for r in rows1] == [r["bpp"] for r in rows2] and b1 == b2
+    assert max(abs(a["psnr"] - b["psnr"]) for a, b in zip(rows1, rows2)) < 1e-5
+    assert all(t > 0 for t in t2)
+    k3 = config3_images()
+    mp = 24 * 512 * 768 * 13 / 1e6
+    compress_with_ac(net, k3[:8], PR_LIST, overlap=True)                                   # warm both objects' workspaces
+    torch.cuda.synchronize()
+    t0 = time.time(); rb = compress_with_ac(net, k3, PR_LIST, batch_same_size=True); torch.cuda.synchronize(); t1 = time.time()
+    ro = compress_with_ac(net, k3, PR_LIST, overlap=True); torch.cuda.synchronize(); t2_ = time.time()
+    assert rb[0] == ro[0]                                                                    # the same bpp column
+    print(f"Config 3 (24 images x 13 levels, encode + decode) through compress_with_ac: batch_same_size {t1 - t0:.2f} s ({mp / (t1 - t0):.1f} level-MP/s), "
+          f"overlap=True {t2_ - t1:.2f} s ({mp / (t2_ - t1):.1f} level-MP/s)")
+
+
+def test_schedule_options_do_not_change_results():
+    """pc_codec_set_option: the product's schedule switches (the tuning builds' environment variables are not in this library).  Same strings and
+    x_hat under every setting; unknown names and bad values are refused."""
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from progressivecodec_amd._lib import PcodecError
+    from tests.util import synth_sd
+    x = torch.rand(6, 3, 128, 128, generator=torch.Generator().manual_seed(9)).cuda()
+    ref = gpu_codec()
+    want = ref.compress(x, 0.5, "point-based-std")
+    want_x = ref.decompress(want["strings"], want["shape"], 0.5, "point-based-std")["x_hat"].clone()
+    net = ChannelProgresssiveWACNN(device="cuda:0")
+    net.load_state_dict(synth_sd())
+    for opts in ({"serial_schedule": 1}, {"serial_schedule": 0, "lanes_enc": 2, "lanes_dec": 1}, {"lanes_enc": 3, "lanes_dec": 3}, {"lanes_enc": 0, "lanes_dec": 0, "host_threads": 2},
+                 {"host_threads": 0, "profile_in_schedule": 1}, {"profile_in_schedule": 0}):
+        for k, v in opts.items():
+            net.set_option(k, v)
+        out = net.compress(x, 0.5, "point-based-std")
+        assert out["strings"] == want["strings"], opts
+        assert torch.equal(net.decompress(out["strings"], out["shape"], 0.5, "point-based-std")["x_hat"], want_x), opts
+    for name, v in (("no_such_option", 1), ("lanes_enc", 9), ("serial_schedule", -1)):
+        with pytest.raises(PcodecError):
+            net.set_option(name, v)
+
+
+def test_reload_of_a_finalised_codec_forgets_the_old_tables():
+    """the reference's REM flow -- load the base net, update(), wrap it, load_state_dict(base, post) on the SAME object with a state
+    dict that lacks the CDF buffers, update() again.  The reload replaces the native handle; the host-side caches of the old handle's tables
+    and scale table must go with it (update() then rebuilds and re-pushes them) -- also when a custom scale table was in force."""
+    from progressivecodec_amd import ChannelProgresssiveWACNN
+    from progressivecodec_amd.synth import synthetic_state_dict
+    sd = synthetic_state_dict()
+    assert "gaussian_conditional._quantized_cdf" not in sd or sd["gaussian_conditional._quantized_cdf"].numel() == 0
+    x = inputs(2, 64, 64, 21).cuda()
+    fresh = ChannelProgresssiveWACNN(device="cuda:0")
+    fresh.load_state_dict(sd)
+    fresh.update()
+    want = fresh.compress(x, 0.5, "point-based-std")["strings"]
+    net = ChannelProgresssiveWACNN(device="cuda:0")
+    net.load_state_dict(sd)
+    assert net.update() is True
+    assert net.compress(x, 0.5, "point-based-std")["strings"] == want
+    net.load_state_dict(sd)                                        # second load on a finalised object: a fresh native handle
+    assert net._gc is None and net._eb is None and net._scale_table is None
+    with pytest.raises(ValueError):
+        net.compress(x, 0.5, "point-based-std")                    # "Uninitialized CDFs. Run update() first"
+    assert net.update() is True
+    assert net.compress(x, 0.5, "point-based-std")["strings"] == want
+    # custom scale table, then a reload of the plain checkpoint: the native side is back on the checkpoint's table and so are the CDFs
+    import math
+    custom = torch.exp(torch.linspace(math.log(0.2), math.log(64), 48))
+    assert net.update(scale_table=custom, force=True) is True
+    other = net.compress(x, 0.5, "point-based-std")["strings"]
+    assert other != want
+    fresh2 = ChannelProgresssiveWACNN(device="cuda:0")
+    fresh2.load_state_dict(sd)
+    fresh2.update(scale_table=custom, force=True)
+    assert fresh2.compress(x, 0.5, "point-based-std")["strings"] == other
+    net.load_state_dict(sd)
+    net.update()
+    assert net.compress(x, 0.5, "point-based-std")["strings"] == want
+    assert net.update(scale_table=custom, force=True) is True      # and the custom table again on the reloaded handle: pushed, not skipped
+    assert net.compress(x, 0.5, "point-based-std")["strings"] == other
+
+
+def test_rem_checkpoint_rep_shape_is_checked_and_never_left_behind():
+    """checkpoint_rep must be [B, 320, H/16, W/16] of the call (the native nets index it with the call's own B and h*w); a call
+    that fails before the native side consumes the pointer must not leave it for the next one."""
+    net = _rem_gpu()
+    x = inputs(2, 64, 64, 5, "smooth").cuda()
+    want = net.compress(x, 0.5, "point-based-std")
+    rep_ok = want["y_hat"]
+    assert tuple(rep_ok.shape) == (2, 320, 4, 4)
+    with_rep = net.compress(x, 1.0, "point-based-std", checkpoint_rep=rep_ok)["strings"]
+    for bad in (rep_ok[:1], rep_ok[:, :, :2], torch.zeros(2, 320, 8, 8), torch.zeros(2, 319, 4, 4), torch.zeros(2, 320, 16)):
+        with pytest.raises(ValueError):
+            net.compress(x, 1.0, "point-based-std", checkpoint_rep=bad)
+        with pytest.raises(ValueError):
+            net.decompress(want["strings"], want["shape"], 0.5, "point-based-std", checkpoint_rep=bad)
+    # a call that fails inside base_net.compress BEFORE the native call (H not a multiple of 64) with a valid checkpoint_rep ...
+    with pytest.raises(ValueError):
+        net.compress(torch.rand(2, 3, 72, 64).cuda(), 1.0, "point-based-std", checkpoint_rep=torch.zeros(2, 320, 4, 4))
+    # ... leaves nothing behind: the next call without a checkpoint_rep gives the plain answer
+    again = net.compress(x, 0.5, "point-based-std")
+    assert again["strings"] == want["strings"]
+    assert net.compress(x, 1.0, "point-based-std", checkpoint_rep=rep_ok)["strings"] == with_rep

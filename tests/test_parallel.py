@@ -91,3 +91,70 @@ def test_bench_refuses_more_ranks_than_gpus():
     env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env2, capture_output=True, text=True, timeout=300)
     assert r.returncode == 2 and "must agree" in r.stderr
+
+
+def _fake_kfd(tmp_path, simd_counts):
+    root = tmp_path / "nodes"
+    for i, sc in enumerate(simd_counts):
+        d = root / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text(f"cpu_cores_count {0 if sc else 64}\nsimd_count {sc}\nmem_banks_count 1\ngfx_target_version {90500 if sc else 0}\n")
+    return str(root)
+
+
+def test_gpu_count_comes_from_the_kfd_topology_not_from_hip(tmp_path, monkeypatch):
+    """count_gpus_without_hip: GPU nodes of the KFD sysfs tree (simd_count > 0; CPU nodes have 0), narrowed by the *_VISIBLE_DEVICES
+    variables -- and torch.cuda is never consulted (VERDICT r03 item 4 / ADVICE r03: the launcher's parent must stay GPU-free)."""
+    from progressivecodec_amd.parallel import count_gpus_without_hip
+
+    def boom(*a, **k):
+        raise AssertionError("the launcher's parent touched torch.cuda")
+    monkeypatch.setattr(torch.cuda, "device_count", boom)
+    monkeypatch.setattr(torch.cuda, "is_available", boom)
+    root = _fake_kfd(tmp_path, [0, 0, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024])       # two CPU sockets + eight MI355X
+    assert count_gpus_without_hip(env={}, sysfs_root=root) == 8
+    assert count_gpus_without_hip(env={"HIP_VISIBLE_DEVICES": "0,1,2"}, sysfs_root=root) == 3
+    assert count_gpus_without_hip(env={"ROCR_VISIBLE_DEVICES": "0,1,2,3", "HIP_VISIBLE_DEVICES": "0,1"}, sysfs_root=root) == 2
+    assert count_gpus_without_hip(env={"CUDA_VISIBLE_DEVICES": ""}, sysfs_root=root) == 0
+    assert count_gpus_without_hip(env={"HIP_VISIBLE_DEVICES": "0,1,2,3,4,5,6,7,8,9,10,11"}, sysfs_root=root) == 8
+    assert count_gpus_without_hip(env={}, sysfs_root=str(tmp_path / "absent"), probe_in_child=False) == 0
+
+
+def test_launcher_parent_never_touches_the_gpu_runtime(tmp_path, monkeypatch):
+    """bench.launch_ranks: counts devices GPU-free, refuses a job larger than the node, and starts exactly N children with the rank
+    environment -- with torch.cuda.* rigged to raise in the parent, and Popen replaced by a recorder (no process is started)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import progressivecodec_amd.parallel as par
+
+    def boom(*a, **k):
+        raise AssertionError("the launcher's parent touched torch.cuda")
+    for name in ("device_count", "is_available", "init", "current_device", "set_device"):
+        monkeypatch.setattr(torch.cuda, name, boom)
+    root = _fake_kfd(tmp_path, [0, 1024, 1024, 1024, 1024])
+    real = par.count_gpus_without_hip
+    monkeypatch.setattr(par, "count_gpus_without_hip", lambda env=None, **kw: real(env=env, sysfs_root=root, probe_in_child=False))
+    for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(k, raising=False)
+    started = []
+
+    class FakeProc:
+        returncode = 0
+
+        def __init__(self, argv, env=None, stdout=None):
+            started.append((argv, env))
+
+        def communicate(self):
+            return b'{"fake": 1}\n', None
+
+        def wait(self):
+            return 0
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    assert bench.launch_ranks(8, ["--gpus", "8"]) == 2 and not started          # four GPUs: an 8-rank job is refused, nothing started
+    assert bench.launch_ranks(4, ["--gpus", "4", "--steps", "3"]) == 0
+    assert len(started) == 4
+    for r, (argv, env) in enumerate(started):
+        assert argv[-4:] == ["--gpus", "4", "--steps", "3"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["LOCAL_WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "4", "4", "127.0.0.1")
+        assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" or "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ
