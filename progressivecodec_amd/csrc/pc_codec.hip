@@ -139,7 +139,7 @@ struct pc_codec {
     // last-call geometry for taps
     int last_B = 0, last_h16 = 0, last_w16 = 0;
 
-    template <typename T> int buf(const std::string& name, size_t count, T** out)
+    template <typename T> int buf(const std::string& name, size_t count, T** out, bool zero_when_allocated = false)
     {
         std::lock_guard<std::mutex> lk(buf_mu);
         DevBuf& d = bufs[name];
@@ -149,6 +149,7 @@ struct pc_codec {
             d.p = nullptr; d.bytes = 0;
             HIPCHK(hipMalloc(&d.p, need));
             d.bytes = need;
+            if (zero_when_allocated) { HIPCHK(hipMemset(d.p, 0, need)); HIPCHK(hipStreamSynchronize(nullptr)); }   // once per size: scratch whose kernels keep it zero between launches (the lanes' streams are non-blocking: the fill must have landed before one of them uses the buffer)
         }
         *out = reinterpret_cast<T*>(d.p);
         return PC_OK;
@@ -1176,7 +1177,7 @@ int quantile_work(const ChainCtx& k, int nb, const std::string& tag, uint32_t** 
 {
     *w = nullptr;
     if ((int64_t)k.HW * SLICE <= PC_QUANTILE_SMALL_N) return PC_OK;
-    return k.c->buf("qwork" + tag, pc_quantile_work_bytes(nb) / sizeof(uint32_t), w);
+    return k.c->buf("qwork" + tag, pc_quantile_work_bytes(nb) / sizeof(uint32_t), w, true);    // all-zero between launches (quantile_onepass_kernel)
 }
 
 int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, hipStream_t st, const std::string& tag)
@@ -1537,6 +1538,22 @@ bool pipeline_enabled(const pc_codec* c)
     return on && !c->serial_profile() && !c->opt_serial;
 }
 
+// Second set of the level-specific buffers of a chain (decoded enhancement slices, per-slice mu / scale / symbols / indexes, mask
+// thresholds): with it the enhancement chains of TWO levels of a multi-level call run side by side -- they depend on the base slices
+// only (CHProg_cnn.py:775-845 / :930-983), never on each other.  Set 0 is the object's ordinary buffers (the taps tests read).
+int second_level_set(pc_codec* c, const ChainCtx& k, bool decoder, ChainCtx* k2)
+{
+    *k2 = k;
+    PCCHK(c->buf("yhat_enh_L2", k.M * D0, &k2->ye));
+    PCCHK(c->buf("mu_L2", k.M * SLICE * 2 * NS0, &k2->mu));
+    PCCHK(c->buf("scale_L2", k.M * SLICE * 2 * NS0, &k2->scale));
+    PCCHK(c->buf("thr_L2", (size_t)k.B * NS0, &k2->thr));
+    PCCHK(c->buf("sym_L2", k.M * SLICE * 2 * NS0, &k2->sym));
+    PCCHK(c->buf("idx_L2", k.M * SLICE * 2 * NS0, &k2->idx));
+    if (decoder) PCCHK(c->buf("idx8_L2", k.M * SLICE * 2 * NS0, &k2->idx8));
+    return PC_OK;
+}
+
 int ensure_pipeline(pc_codec* c, size_t M)
 {
     if (!c->pipe_stream) {
@@ -1572,7 +1589,14 @@ struct CallOrder {
         if (!c->call_done) { if (hipEventCreateWithFlags(&c->call_done, hipEventDisableTiming) != hipSuccess) { c->call_done = nullptr; rc = PC_ERR_HIP; } }
         else if (hipStreamWaitEvent(st, c->call_done, 0) != hipSuccess) rc = PC_ERR_HIP;
     }
-    ~CallOrder() { if (c->call_done) (void)hipEventRecord(c->call_done, st); }
+    ~CallOrder()
+    {
+        // whatever path the call left by: work it queued on the object's second chain stream is joined into the caller's stream first
+        // (a failed call must not leave a chain of its own running beside the next call)
+        if (c->pipe_stream && c->pipe_ev.size() > (size_t)NS0 + 1 && hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream) == hipSuccess)
+            (void)hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0);
+        if (c->call_done) (void)hipEventRecord(c->call_done, st);
+    }
 };
 
 // compress() for a list of mask levels.  Everything that does not depend on the level -- g_a, h_a, the hyper-latent
@@ -1665,6 +1689,15 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
         return PC_OK;
     };
     const bool piped = pipeline_enabled(c) && first_coded >= 0 && lane_count(c, B, false) == 1;
+    // Two levels in flight (round 4): with more than one coded level the enhancement chains alternate between two buffer sets and two
+    // streams -- level j of the coded ones on pipe_stream / set 0 (j even) or on `st` / set 1 (j odd) -- so that level j+1's chain runs
+    // beside level j's instead of behind it (the chains are independent; each alone leaves the MFMA pipes as idle as a sequential
+    // Config-2 step does).  The host codes level j-1 while both run, as before.
+    int n_coded_total = 0;
+    for (int l = 0; l < n_levels; ++l) n_coded_total += !(qualities[l] <= 0) ? 1 : 0;
+    const bool two_levels = piped && !can_stream && n_coded_total >= 2;
+    ChainCtx k2;
+    if (two_levels) PCCHK(second_level_set(c, k, false, &k2));
     if (piped) {
         // base slice t on `st`, enhancement slice t-1 of the first coded level on pipe_stream, enqueued alternately
         PCCHK(ensure_pipeline(c, M));
@@ -1688,8 +1721,10 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
                 PCCHK(encode_lane(ke, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB"));   // :775-845
             }
         }
-        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
-        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+        if (!two_levels) {                                                                // (two levels in flight: `st` goes on with the next level; joined at the end)
+            HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
+            HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
+        }
     } else {
         k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
         PCCHK(run_chain(k, st, false, nullptr, nullptr));                                // :729-767
@@ -1750,6 +1785,25 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
             t_host += now() - te;
             continue;
         }
+        if (two_levels) {
+            // coded level number n_coded: even -> set 0 on pipe_stream (the first one is already enqueued there, pipelined with the base
+            // chain), odd -> set 1 on `st` (behind the base chain, which it needs and which ran there)
+            const bool odd = n_coded & 1;
+            ChainCtx kl = odd ? k2 : k;
+            kl.step0 = NS0; kl.step1 = 2 * NS0; kl.enh = true; kl.level = l; kl.mode = k.mode; kl.q = k.q; kl.quality = k.quality; kl.mask_pol = k.mask_pol;
+            kl.masks = k.masks;
+            hipStream_t sx = odd ? st : c->pipe_stream;
+            if (!pre) PCCHK(encode_lane(kl, 0, B, sx, sx, nullptr, nullptr, odd ? "PA" : "PB"));   // :775-845
+            HIPCHK(hipMemcpyAsync(c->h_sym + off, kl.sym + n_half, n_half * 4, hipMemcpyDeviceToHost, sx));
+            HIPCHK(hipMemcpyAsync(c->h_idx + off, kl.idx + n_half, n_half * 4, hipMemcpyDeviceToHost, sx));
+            HIPCHK(hipEventRecord(c->lvl_events[1 + l], sx));
+            c->res_level_coded[l] = 1;
+            ++n_coded;
+            const int r = drain(pending, pending_buf);                                   // the level before last, meanwhile
+            if (r != PC_OK) rc = r;
+            pending = l; pending_buf = bufsel;
+            continue;
+        }
         if (!pre) PCCHK(run_chain(k, st, false, nullptr, nullptr));                      // :775-845
         HIPCHK(hipMemcpyAsync(c->h_sym + off, k.sym + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipMemcpyAsync(c->h_idx + off, k.idx + n_half, n_half * 4, hipMemcpyDeviceToHost, st));
@@ -1764,6 +1818,10 @@ int compress_impl(pc_codec* c, const float* x, int B, int H, int W, const double
     if (pending != -2) {
         const int r = drain(pending, pending_buf);
         if (r != PC_OK) rc = r;
+    }
+    if (two_levels) {                                                                    // pipe_stream back into the caller's stream
+        HIPCHK(hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream));
+        HIPCHK(hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0));
     }
     HIPCHK(hipStreamSynchronize(st));                                                    // masks_out complete for the caller
     c->t_compress_ms = now() - t0; c->t_host_encode_ms = t_host; c->t_host_encode_exposed_ms = t_enc_last;
@@ -2006,6 +2064,48 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :874-904
     }
     const size_t img_elems = (size_t)B * 3 * (16 * h) * (16 * w);
+    // Two levels in flight (round 4): the enhancement chains of the levels that are still to decode are independent of each other, and a
+    // chain alone leaves the GPU idle through every slice's host entropy decode (at 4K: 93 of 148 ms).  They are decoded in PAIRS -- one
+    // level on `st` (own host thread, buffer set 1), the other on pipe_stream (this thread, set 0) -- so that each chain's host round trip
+    // hides behind the other's kernels, as the base || first-level pipeline above does; the synthesis transforms follow on `st`.
+    std::vector<int> rest;
+    for (int l = 0; l < n_levels; ++l) if (qualities[l] != 0 && !(piped && l == first_enh)) rest.push_back(l);
+    if (piped && !rest.empty()) {
+        ChainCtx k2;
+        PCCHK(second_level_set(c, k, true, &k2));
+        for (int l = 0; l < n_levels; ++l) if (qualities[l] == 0) PCCHK(g_s(c, st, c->gs[0], k.yb, B, h, w, x_hat + (size_t)l * img_elems));   // :907-916
+        PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, x_hat + (size_t)first_enh * img_elems));                                               // :986-990
+        auto level_ctx = [&](const ChainCtx& base, int l, size_t h_off) {
+            ChainCtx q = base;
+            q.step0 = NS0; q.step1 = 2 * NS0; q.enh = true; q.level = l; q.waitv = nullptr; q.wait_count = nullptr; q.sig = nullptr; q.sig_count = nullptr;
+            q.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &q.q);
+            q.quality = qualities[l]; q.mask_pol = mask_pol; q.h_off = h_off;
+            return q;
+        };
+        for (size_t p = 0; p < rest.size(); p += 2) {
+            const int la = rest[p], lb = p + 1 < rest.size() ? rest[p + 1] : -1;
+            const ChainCtx ka = level_ctx(k2, la, 0);
+            int ra = PC_OK, rb = PC_OK;
+            if (lb >= 0) {
+                const ChainCtx kb2 = level_ctx(k, lb, per * B);
+                HIPCHK(hipEventRecord(c->pipe_ev[NS0], st));                             // set 0 is free once the g_s that read it has run
+                HIPCHK(hipStreamWaitEvent(c->pipe_stream, c->pipe_ev[NS0], 0));
+                std::thread ta([&] { ra = decode_lane(ka, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt); });
+                rb = decode_lane(kb2, 0, B, c->pipe_stream, c->pipe_stream, nullptr, nullptr, "PB", y_strings, y_lens, nt);
+                ta.join();
+                const hipError_t ej = hipEventRecord(c->pipe_ev[NS0 + 1], c->pipe_stream);
+                const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(st, c->pipe_ev[NS0 + 1], 0) : ej;
+                if (ra != PC_OK || rb != PC_OK) { (void)hipStreamSynchronize(c->pipe_stream); (void)hipStreamSynchronize(st); }
+                if (ra != PC_OK) return ra;
+                if (rb != PC_OK) return rb;
+                HIPCHK(ew);
+            } else {
+                PCCHK(decode_lane(ka, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt));
+            }
+            PCCHK(g_s(c, st, c->gs[1], ka.ye, B, h, w, x_hat + (size_t)la * img_elems));
+            if (lb >= 0) PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, x_hat + (size_t)lb * img_elems));
+        }
+    } else
     for (int l = 0; l < n_levels; ++l) {
         float* out = x_hat + (size_t)l * img_elems;
         if (qualities[l] == 0) {

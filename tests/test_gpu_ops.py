@@ -306,3 +306,23 @@ def test_gc_prep_encode_and_decode_bit_exact(hw, mode, delta):
         assert np.array_equal(msk.cpu().numpy(), tr(m))
     assert np.array_equal(yhat.cpu().numpy().view(np.uint32), yhat_w.view(np.uint32))
     assert np.array_equal(yhat2.cpu().numpy().view(np.uint32), yhat_w.view(np.uint32))
+
+
+def test_quantile_one_launch_repeated_calls_and_changing_batch():
+    """The one-launch quantile (quantile_onepass_kernel) keeps its scratch all-zero between launches: the same stream's buffer is used by
+    calls of different batch and image sizes, back to back with no host synchronisation in between, and every threshold must still be
+    the exact order statistic (a header left non-zero, or a ticket counter not rewound, would show as a wrong or hanging later call)."""
+    L, check = _lib()
+    rng = np.random.default_rng(77)
+    cases = [(3, 4096, 0.5), (1, 5000, 2.0), (7, 2048, 9.0), (2, 70000, 0.05), (5, 1500, 5.0), (3, 4096, 0.5), (1, 65281, 1.0), (16, 1100, 3.0), (4, 4096, 7.5)]
+    scales = [(0.6 + 0.7 * rng.standard_normal((B, hw, 32))).astype(np.float32) for B, hw, _ in cases]
+    scales[2][0] = np.round(scales[2][0] * 8) / 8
+    devs = [dev(s) for s in scales]
+    outs = [torch.empty(B, device="cuda", dtype=torch.float32) for B, _, _ in cases]
+    for rep in range(3):
+        for (B, hw, pr), sd, thr in zip(cases, devs, outs):
+            check(L.pc_mask_quantile_threshold(P(sd), 32, B, hw, 32, np.float32(1.0 - pr * 0.1), P(thr), None))
+    torch.cuda.synchronize()
+    for (B, hw, pr), sc, thr in zip(cases, scales, outs):
+        want = np.array([lo.quantile(sc[b], np.float32(1.0 - pr * 0.1)) for b in range(B)], np.float32)
+        assert np.array_equal(thr.cpu().numpy().view(np.uint32), want.view(np.uint32)), (B, hw, pr)

@@ -1,7 +1,11 @@
 #!/bin/bash
 # The GPU test suite (minus the full-size Config 4 / 5 cases) under the run-time switches that select kernels, tiles, stages, lanes,
 # pipelining and host threads: every configuration must give the same bits.  usage (through gpurun): bash tools/env_matrix.sh > log
+# Since round 4 the switches exist only in the TUNING build of the library (csrc/Makefile `tuning`: -DPC_TUNING -> libpcodec_tuning.so, the
+# same sources); the matrix runs the suite against it (PC_LIB).  The product library ignores these variables.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
+export PC_LIB=$R/progressivecodec_amd/libpcodec_tuning.so
+[ -f "$PC_LIB" ] || { echo "build the tuning library first: make -C progressivecodec_amd/csrc tuning"; exit 2; }
 fail=0
 ONLY=${1:-}
 run() {
@@ -21,6 +25,7 @@ run PC_CONV_S=3 PC_CONV_TM=2
 run PC_CONV_TM=2 PC_CONV_TN=2
 run PC_CONV_ROWPERM=0
 run PC_CONV_ROWPERM_MIN=0
+run PC_CONV_GROUP_XCD=0
 run PC_PREP_SCALAR=1
 run PC_DEC_FAST=0
 run PC_LANES=1

@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of bench.py under environment switches on ONE box: usage  bash tools/gpu_ab.sh "NAME=VAL ..." "NAME=VAL ..." ...   (each arm run twice, interleaved)
+# A/B of bench.py under environment switches on ONE box (the switches live in the tuning build: export PC_LIB=.../libpcodec_tuning.so first): usage  bash tools/gpu_ab.sh "NAME=VAL ..." "NAME=VAL ..." ...   (each arm run twice, interleaved)
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; cd $R
 for rep in 1 2; do
   for arm in "$@"; do

@@ -7,16 +7,18 @@ TAG=${1:-r03_x}
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; P=$O/profiles_$TAG; mkdir -p $P
 cd /tmp && export TMPDIR=/tmp
 rm -rf $O/prof_stats_default $O/prof_stats_1lane $O/pmc_FETCH $O/pmc_WRITE $O/prof_stage $O/pmc_stage_FETCH $O/pmc_stage_WRITE $O/pmc_clk_serial
-# serial form: one lane, one stream, no pipelining inside the codec and no encoder / decoder overlap -- a launch's duration is its own
-SER="PC_LANES=1 PC_DUAL_STREAM=0 PC_PIPELINE=0"
+# serial form: one lane, one stream, no pipelining inside the codec (pc_codec_set_option "serial_schedule": bench.py --serial-schedule) and no
+# encoder / decoder overlap -- a launch's duration is its own
+SER="PC_UNUSED=0"
+SS="--serial-schedule"
 # (--lean: the timed steps, the enc/dec split and the roofline leg only -- no CPU baseline, no rANS leg, no second sequential run)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_default -o run -- python3 $R/bench.py --steps 30 --warmup 2 --lean > $O/prof_stats_default.log 2>&1 || exit 1
 echo "default stats done"
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 > $O/prof_stats_1lane.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof_stats_1lane -o run -- python3 $R/bench.py --steps 5 --warmup 1 --lean --overlap 0 $SS > $O/prof_stats_1lane.log 2>&1 || exit 1
 echo "1lane stats done"
-env $SER PC_PROFILE_CSV=$O/pmc_FETCH_launches.csv timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_FETCH -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_FETCH.log 2>&1 || exit 1
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_WRITE -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 > $O/pmc_WRITE.log 2>&1 || exit 1
-env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_clk_serial -o run -- python3 $R/bench.py --steps 2 --warmup 1 --lean --overlap 0 > $O/pmc_clk_serial.log 2>&1 || exit 1
+env $SER PC_PROFILE_CSV=$O/pmc_FETCH_launches.csv timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_FETCH -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 $SS > $O/pmc_FETCH.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_WRITE -o runc -- python3 $R/bench.py --steps 1 --warmup 1 --lean --overlap 0 $SS > $O/pmc_WRITE.log 2>&1 || exit 1
+env $SER timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES --output-format csv -d $O/pmc_clk_serial -o run -- python3 $R/bench.py --steps 2 --warmup 1 --lean --overlap 0 $SS > $O/pmc_clk_serial.log 2>&1 || exit 1
 echo "pmc done"
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/prof_stage -o run -- python3 $R/tools/stage_bench.py 256 > $O/prof_stage.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_stage_FETCH -o runc -- python3 $R/tools/stage_bench.py 256 > $O/pmc_stage_FETCH.log 2>&1 || exit 1

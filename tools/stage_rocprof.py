@@ -10,7 +10,8 @@ GB/s they make at the trace's duration, next to the algorithmic figure (VERDICT 
 
 stage_bench.py calls, in this order: the quantile once, then (1 + 10) times each of: quantile, encoder enhancement prep, encoder base
 prep, decoder index, dequantise.  The kernel trace is cut into those calls by start time; a call of the quantile on a Config-4 slice
-is three kernels (sample / bracket / final), every other call is one kernel; the per-kernel averages are reported too."""
+was three kernels (sample / bracket / final) until round 3 and is one (quantile_onepass_kernel) since round 4; every other call is one kernel;
+the per-kernel averages are reported too."""
 import csv
 import glob
 import json
@@ -37,7 +38,7 @@ def segment(ks):
         one = any(t in name for t in ("gc_prep_kernel<1>", "gc_prep_kernelILi1", "gc_prep_vec_kernel<1", "gc_prep_vec_kernelILi1"))
         key = "quantile" if "quantile" in name else ("gc_prep_kernel<0>" if zero else ("gc_prep_kernel<1>" if one else "gc_dequant"))
         if key == "quantile":
-            if cur is None or cur[0] != "quantile" or "sample" in name or ("thr_kernel" in name):
+            if cur is None or cur[0] != "quantile" or "sample" in name or "thr_kernel" in name or "onepass" in name:
                 cur = ["quantile", 0, 0]
                 calls.append(cur)
             cur[1] += ns; cur[2] += 1
