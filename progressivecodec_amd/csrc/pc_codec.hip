@@ -168,12 +168,14 @@ int launch_conv(const pc_conv_params& q_in, hipStream_t st)
     long taps = 0;
     for (int ph = 0; ph < q.nphase; ++ph) taps += q.ntap[ph];
     const double ng = q.ngroup == 2 ? 2.0 : 1.0;
-    const double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin * ng;
+    double fl = 2.0 * (double)q.M * (double)q.Cout * (double)taps * (double)q.Cin * ng;
+    if (q.fg_gamma) fl += 2.0 * (double)q.M * (double)q.Cout * (double)q.Cout;          // the fused GDN's 1x1 contraction
     // algorithmic HBM bytes of the launch (SURVEY.md section 8d style: every operand once): the input tensor once (all segments; a
     // grouped launch reads a second first segment), the weights and bias of every phase / group, the output once, each aux tensor once
     double by = 0.0;
     for (int sg = 0; sg < q.nseg; ++sg) by += 4.0 * (double)q.B * q.H * q.W * q.seg[sg].nch * (sg == 0 ? ng : 1.0);
     by += ng * 4.0 * ((double)taps * q.Cin * q.Cout + q.Cout);
+    if (q.fg_gamma) by += 4.0 * ((double)q.Cout * q.Cout + q.Cout);
     by += ng * 4.0 * (double)q.nphase * q.M * q.Cout;
     if (q.aux0 && q.epi != PC_EPI_NONE && q.epi != PC_EPI_GELU && q.epi != PC_EPI_CLAMP01) by += 4.0 * (double)q.nphase * q.M * q.Cout;
     if (q.aux1 && (q.epi == PC_EPI_GATE || q.epi == PC_EPI_LRP_ADD)) by += 4.0 * (double)q.nphase * q.M * q.Cout;
@@ -558,10 +560,11 @@ int g_a_net(pc_codec* c, hipStream_t st, const pc_codec::GaW& g, const float* x,
         fill_conv_taps(q, 5, 2);
         q.w = g.c0.w; q.bias = g.c0.b; q.Cout = NCH;
         q.Ho = H / 2; q.Wo = W / 2; q.outH = q.Ho; q.outW = q.Wo; q.M = B * q.Ho * q.Wo;
-        q.out = t0; q.out_sc = 1; q.out_sx = NCH; q.out_sy = (int64_t)q.Wo * NCH; q.out_sb = (int64_t)q.Ho * q.Wo * NCH;
+        // g_a.1 (GDN) rides in the same kernel: the 192-channel conv output never leaves the workgroup's LDS (round 4)
+        q.fg_gamma = g.g1.gamma; q.fg_beta = g.g1.beta;
+        q.out = t1; q.out_sc = 1; q.out_sx = NCH; q.out_sy = (int64_t)q.Wo * NCH; q.out_sb = (int64_t)q.Ho * q.Wo * NCH;
         PCCHK(launch_conv(q, st));
     }
-    PCCHK(gdn(st, g.g1, t0, B, H / 2, W / 2, false, t1));
     PCCHK(conv(st, g.c2, {{t1, NCH, NCH}}, B, H / 2, W / 2, 2, t2, NCH, PC_EPI_NONE));
     PCCHK(gdn(st, g.g3, t2, B, H / 4, W / 4, false, t3));
     PCCHK(wam(c, st, g.w4, t3, B, H / 4, W / 4, t2));
@@ -1177,7 +1180,7 @@ int quantile_work(const ChainCtx& k, int nb, const std::string& tag, uint32_t** 
 {
     *w = nullptr;
     if ((int64_t)k.HW * SLICE <= PC_QUANTILE_SMALL_N) return PC_OK;
-    return k.c->buf("qwork" + tag, pc_quantile_work_bytes(nb) / sizeof(uint32_t), w, true);    // all-zero between launches (quantile_onepass_kernel)
+    return k.c->buf("qwork" + tag, pc_quantile_work_bytes(nb) / sizeof(uint32_t), w);
 }
 
 int mask_threshold(const ChainCtx& k, int i, int b0, int nb, const float* sc_i, hipStream_t st, const std::string& tag)

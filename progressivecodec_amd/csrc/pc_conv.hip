@@ -312,6 +312,187 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 
 
 // ------------------------------------------------------------------------------------------
+// g_a.0 + g_a.1 in ONE kernel (round 4): the 3 -> 192 input convolution (5x5 s2, element gather
+// from the NCHW image; models/cnn.py:34-35, models/utils.py:186-193) and the GDN that consumes it (layers/gdn.py:50-63).  As two
+// launches the pair wrote the 192-channel tensor (402 MB at Config 2), read it back twice (GEMM operand + epilogue) and wrote the
+// normalised tensor: 0.93 ms for 26.9 GFLOP.  Here a workgroup owns 64 pixels x ALL 192 channels (2 x 2 waves, wave tile 32 x 96 =
+// three accumulators): phase 1 is conv_igemm_kernel's SMALLC loop (K = 75 in five 16-chunks); x = chain + bias goes to LDS k-major
+// ([channel][pixel]) -- exactly the A image phase 2 needs; phase 2 contracts x^2 with gamma (K = 192, gamma chunks double-buffered
+// through LDS) and the epilogue reads x back from the same image: out = x * rsqrt(beta + norm).  Per output element the two fmaf
+// chains, the bias adds, the square and the rsqrt are those of the two-launch form (same k order, same operations): bit-identical.
+// LDS: 192 x 65 floats of x + 2 x 16 x 196 of weights = 75 008 B -> two workgroups per CU.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1_gdn_fused_kernel(const pc_conv_params p)
+{
+    constexpr int BM = 64, CN = 192, BK = 16, TN = 3;
+    constexpr int LDX = BM + 1, LDA = BM + 4, LDB = CN + 4;
+    extern __shared__ float fsm[];
+    float* Xs = fsm;                                   // [CN][LDX]
+    float* Bs = Xs + CN * LDX;                         // phase 2: 2 x [BK][LDB]; phase 1: [BK][LDB] weights, then [BK][LDA] pixels
+    float* As = Bs + BK * LDB;
+    int* ktab = reinterpret_cast<int*>(Bs + 2 * BK * LDB);   // [2][80]: per flattened k = tap * Cin + c, the element offset from the pixel's (iy0, ix0) and dy << 16 | dx
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int T = p.ntap[0];
+    const int HoWo = p.Ho * p.Wo;
+    const int Ktot = T * p.Cin;
+
+    // ---- phase 1: this thread gathers 4 consecutive k of one pixel row per chunk; 3 float4 of weights.  lane = pixel row, wave = k-quad:
+    // one load instruction then reads ONE (tap, channel) for 64 neighbouring output pixels -- addresses two floats apart along an image
+    // row -- instead of sixteen pixels x four different taps (conv_igemm_kernel's mapping: 876 -> 8xx us for the fused pair)
+    const int kq = wave, a_row = lane;
+    const int64_t am = m0 + a_row;
+    const bool a_ok = am < (int64_t)p.M;
+    int a_iy0, a_ix0;
+    int64_t a_b;
+    {
+        const int64_t mm = a_ok ? am : 0;
+        a_b = mm / HoWo;
+        const int r = (int)(mm - a_b * HoWo);
+        const int oy = r / p.Wo, ox = r - oy * p.Wo;
+        a_iy0 = oy * p.stride; a_ix0 = ox * p.stride;
+    }
+    const float* xin = p.seg[0].ptr + a_b * p.in_sb + (int64_t)a_iy0 * p.in_sy + (int64_t)a_ix0 * p.in_sx;
+    if (tid < 80) {                                     // the k -> (tap, channel) division once per workgroup, not once per gathered element
+        int o = 0, d = 0;
+        if (tid < Ktot) {
+            const int t = tid / p.Cin, c = tid - t * p.Cin;
+            o = (int)((int64_t)p.dy[0][t] * p.in_sy + (int64_t)p.dx[0][t] * p.in_sx + (int64_t)c * p.in_sc);
+            d = (p.dy[0][t] << 16) | (p.dx[0][t] & 0xffff);
+        }
+        ktab[tid] = o; ktab[80 + tid] = d;
+    }
+    __syncthreads();
+    constexpr int BQ = CN / 4;
+    int b_k[3], b_n[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + i * 256; b_k[i] = e / BQ; b_n[i] = (e % BQ) * 4; }
+
+    f32x16 acc[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.0f;
+
+    float4 ra, rb[3];
+    auto load1 = [&](int chunk) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kf = chunk * BK + kq * 4 + j;
+            float x = 0.0f;
+            if (a_ok && kf < Ktot) {
+                const int d = ktab[80 + kf];
+                const int iy = a_iy0 + (d >> 16), ix = a_ix0 + (int)(short)(d & 0xffff);
+                if (iy >= 0 && iy < p.H && ix >= 0 && ix < p.W) x = xin[ktab[kf]];
+            }
+            v[j] = x;
+        }
+        ra = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int kf = chunk * BK + b_k[i];
+            rb[i] = kf < Ktot ? *reinterpret_cast<const float4*>(p.w + (int64_t)kf * CN + b_n[i]) : make_float4(0.f, 0.f, 0.f, 0.f);   // w[t][c][n] == w[kf][n]
+        }
+    };
+    auto store1 = [&]() {
+        As[(kq * 4 + 0) * LDA + a_row] = ra.x;
+        As[(kq * 4 + 1) * LDA + a_row] = ra.y;
+        As[(kq * 4 + 2) * LDA + a_row] = ra.z;
+        As[(kq * 4 + 3) * LDA + a_row] = ra.w;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(Bs + b_k[i] * LDB + b_n[i]) = rb[i];
+    };
+    const int nch1 = (Ktot + BK - 1) / BK;
+    load1(0);
+    for (int chunk = 0; chunk < nch1; ++chunk) {
+        store1();
+        __syncthreads();
+        if (chunk + 1 < nch1) load1(chunk + 1);                          // in flight under this chunk's MFMAs
+        const float* a = As + wm * 32 + l31;
+        const float* b = Bs + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            const int kk = (st >> 2) * 8 + (st & 3) + 4 * half;           // the contract's in-group order 0,4,1,5,2,6,3,7
+            const float av = a[kk * LDA];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk * LDB + j * 32], acc[j], 0, 0, 0);
+        }
+        __syncthreads();                                                  // single-buffered: everyone is done reading before the next store
+    }
+    // x = conv + bias -> LDS, k-major
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * (TN * 32) + j * 32 + l31;
+        const float bv = p.bias ? p.bias[n] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[j][r];
+            if (p.bias) v = v + bv;
+            Xs[n * LDX + row] = v;
+            acc[j][r] = 0.0f;
+        }
+    }
+    // ---- phase 2: norm = gamma . x^2 (K = 192), gamma in layout 1 ([n][k]); chunk c in buffer c & 1
+    int g_n[3], g_q[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { const int e = tid + i * 256; g_n[i] = e >> 2; g_q[i] = e & 3; }
+    auto load2 = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const float4*>(p.fg_gamma + (int64_t)g_n[i] * CN + chunk * BK + g_q[i] * 4);
+    };
+    auto store2 = [&](int buf) {
+        float* b = Bs + buf * BK * LDB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            b[(g_q[i] * 4 + 0) * LDB + g_n[i]] = rb[i].x;
+            b[(g_q[i] * 4 + 1) * LDB + g_n[i]] = rb[i].y;
+            b[(g_q[i] * 4 + 2) * LDB + g_n[i]] = rb[i].z;
+            b[(g_q[i] * 4 + 3) * LDB + g_n[i]] = rb[i].w;
+        }
+    };
+    load2(0);
+    store2(0);
+    __syncthreads();                                                      // x image and gamma chunk 0 in place
+    constexpr int NCH2 = CN / BK;
+    for (int chunk = 0; chunk < NCH2; ++chunk) {
+        const int cur = chunk & 1;
+        if (chunk + 1 < NCH2) load2(chunk + 1);
+        const float* a = Xs + (chunk * BK) * LDX + wm * 32 + l31;
+        const float* b = Bs + cur * BK * LDB + wn * (TN * 32) + l31;
+#pragma unroll
+        for (int st = 0; st < BK / 2; ++st) {
+            const int kk = (st >> 2) * 8 + (st & 3) + 4 * half;
+            float av = a[kk * LDX];
+            av = av * av;                                                 // gdn.py:56: the contraction runs over x^2
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk * LDB + j * 32], acc[j], 0, 0, 0);
+        }
+        if (chunk + 1 < NCH2) store2(cur ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue: out = x * rsqrt(beta + norm), NHWC
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = wn * (TN * 32) + j * 32 + l31;
+        const float bv = p.fg_beta[n];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int64_t m = m0 + row;
+            if (m >= (int64_t)p.M) continue;
+            const float v = acc[j][r] + bv;
+            p.out[m * p.out_sx + n] = Xs[n * LDX + row] * pc_rsqrtf(v);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------
 // LDS-DMA implicit GEMM (weight layout 1): shared pieces.  `buffer_load_dwordx4 ... lds` moves 16 B per lane straight into LDS
 // (no VGPR staging, no ds_write); the LDS image is [row][k-quad] 16-byte pieces with an XOR swizzle on the SOURCE address (LDS-DMA
 // writes lane-linearly), read back conflict-free with ds_read_b128; weights are pre-packed [tap][Cout][Cin] (K contiguous per
@@ -1396,6 +1577,24 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
     //  * weight layout 0: the plain BK=16 kernel -- the 3-channel output layer and the 3-channel input layer (element-gather
     //    loader).  (1x1 convs and GDN moved to the LDS-DMA kernel: 17-25 % faster, profiles/r01_tune_tune27.log.)
     hipError_t e;
+    if (p.fg_gamma) {
+        // the input layer with its GDN fused (conv1_gdn_fused_kernel): 3 -> 192, one phase, dense NHWC output of 192 channels
+        if (!p.smallc || p.wlayout != 0 || p.Cout != 192 || p.nphase != 1 || !p.dense_out || p.out_sc != 1 || !p.fg_beta || p.epi != PC_EPI_NONE ||
+            p.ngroup == 2 || p.ntap[0] * p.Cin > 80)
+            return PC_ERR_ARG;
+        constexpr size_t lds = (size_t)(192 * 65 + 2 * 16 * 196 + 2 * 80) * sizeof(float);
+        if ((int64_t)3 * p.H * p.W >= ((int64_t)1 << 31)) return PC_ERR_ARG;             // (element offsets inside one image are 32-bit)
+        static std::atomic<uint32_t> attr_set{0};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (!(attr_set.load(std::memory_order_acquire) & (1u << (dev & 31)))) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_gdn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return PC_ERR_HIP;
+            attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
+        }
+        hipLaunchKernelGGL(conv1_gdn_fused_kernel, dim3((unsigned)((p.M + 63) / 64)), dim3(256), lds, stream, p);
+        return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
+    }
     if (p.wlayout == 1) {
         if (p.smallc || (p.Cin % 16)) return PC_ERR_ARG;
         if (p.ngroup == 2 && (p.nphase != 1 || !p.g1_seg0 || !p.g1_w || !p.g1_out)) return PC_ERR_ARG;

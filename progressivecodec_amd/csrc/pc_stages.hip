@@ -9,10 +9,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <algorithm>
-#include <mutex>
-#include <vector>
-
 #include "../../include/pc_math.h"
 #include "pc_device.h"
 
@@ -155,10 +151,10 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* hist, uint32_t bin, bool
 }
 
 // One workgroup selects the order statistics lo = floor(q*(n_total-1)) and lo+1 of one image and writes the interpolated threshold.
-// (NT threads.)  EPT > 0: the n_scan <= NT*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per
+// EPT > 0: the n_scan <= 1024*EPT keys are read ONCE and live in registers across the radix passes; EPT == 0: any n, re-read per
 // pass.  CAND: the keys come from a candidate list (multi-block path below) that holds every element of the histogram bins
 // containing the two ranks; less0 elements of the image lie below those bins, nan0 NaNs were seen by the histogram pass.
-template <int EPT, bool CAND, int NT = 1024>
+template <int EPT, bool CAND>
 __device__ __forceinline__ void quantile_block(const float* __restrict__ base, int ld, int C, const uint32_t* __restrict__ cand,
                                                int64_t n_scan, int64_t n_total, uint32_t less0, uint32_t nan0, float q, float* out)
 {
@@ -179,7 +175,7 @@ __device__ __forceinline__ void quantile_block(const float* __restrict__ base, i
     if (EPT > 0) {
 #pragma unroll
         for (int i = 0; i < NK; ++i) {
-            const int64_t e = tid + NT * (int64_t)i;
+            const int64_t e = tid + 1024 * (int64_t)i;
             keys[i] = e < n ? key_at(e, nan_local) : 0u;
         }
     }
@@ -193,20 +189,20 @@ __device__ __forceinline__ void quantile_block(const float* __restrict__ base, i
     uint32_t prefix_mask = 0;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
-        for (int k = tid; k < 256; k += NT) hist[k] = 0;
+        for (int k = tid; k < 256; k += 1024) hist[k] = 0;
         __syncthreads();
         const uint32_t prefix = sh_prefix;
         if (EPT > 0) {
 #pragma unroll
             for (int i = 0; i < NK; ++i) {
-                const bool in = tid + NT * (int64_t)i < n;
+                const bool in = tid + 1024 * (int64_t)i < n;
                 const uint32_t bin = (keys[i] >> shift) & 255u;
                 if (pass == 0) hist_add_wave(hist, bin, in);                 // clustered digits: aggregate per wave
                 else if (in && (keys[i] & prefix_mask) == prefix) atomicAdd(&hist[bin], 1u);   // few survivors, spread digits
             }
         } else {
             uint32_t nan_pass = 0;
-            for (int64_t e = tid; e < n; e += NT) {           // large images: plain LDS atomics measured faster than aggregation here
+            for (int64_t e = tid; e < n; e += 1024) {         // large images: plain LDS atomics measured faster than aggregation here
                 const uint32_t k = key_at(e, nan_pass);
                 if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
             }
@@ -245,9 +241,9 @@ __device__ __forceinline__ void quantile_block(const float* __restrict__ base, i
         uint32_t mn = 0xffffffffu, dummy = 0;
         if (EPT > 0) {
 #pragma unroll
-            for (int i = 0; i < NK; ++i) { const uint32_t k = keys[i]; if (tid + NT * (int64_t)i < n && k > key_lo && k < mn) mn = k; }
+            for (int i = 0; i < NK; ++i) { const uint32_t k = keys[i]; if (tid + 1024 * (int64_t)i < n && k > key_lo && k < mn) mn = k; }
         } else {
-            for (int64_t e = tid; e < n; e += NT) { const uint32_t k = key_at(e, dummy); if (k > key_lo && k < mn) mn = k; }
+            for (int64_t e = tid; e < n; e += 1024) { const uint32_t k = key_at(e, dummy); if (k > key_lo && k < mn) mn = k; }
         }
         for (int off = 32; off; off >>= 1) { const uint32_t o = __shfl_xor(mn, off); mn = o < mn ? o : mn; }
         if ((tid & 63) == 0) atomicMin(&sh_min, mn);
@@ -287,6 +283,12 @@ __global__ __launch_bounds__(1024) void quantile_thr_kernel(const float* __restr
 //      the quantile than the list holds -- falls back to the generic select over the whole image, so the result is always the exact
 //      order statistic.
 // work (uint32 per image, stride PC_QW_STRIDE): nan count, candidate count, key a, key b, less, pad[3], then PC_QW_CAP candidates.
+// Round 4 built the three steps as ONE launch (blocks with ticketed ids, the image's producer block
+// publishing the bracket, the last block of an image selecting) and measured it on the Config-4 slice: 0.26-0.43 ms against the 0.055 ms of
+// the three launches below, results identical.  On an 8-XCD part every block-to-block hand-over inside a kernel is a device-scope
+// release / acquire -- an L2 write-back / invalidate per wave or per block (the XCDs' L2s are not coherent with each other) -- and 2048
+// blocks x those cost five times what the two kernel boundaries cost, which do the same once for the whole chip.  Rejected by
+// measurement: profiles/r04_d_quantile_one_launch_probe.log (the kernel: pc_stages.hip at commit 8ee4ee6).
 #define PC_QW_CAP 32768
 #define PC_QW_HDR 8
 #define PC_QW_STRIDE (PC_QW_HDR + PC_QW_CAP)
@@ -328,143 +330,115 @@ __device__ __forceinline__ uint32_t sample_prefix(const uint32_t (&k)[16], uint3
     return prefix >> 12;
 }
 
-// ---- round 4: the three steps in ONE launch (rounds 1-3 ran them as three kernels -- sample 13 us, bracket
-// 34 us, final 8 us on a Config-4 slice, profiles/r03_zz_stage_kernels_rocprof.json).
-// Blocks take DYNAMIC ids from a ticket counter (image = ticket / G, x = ticket % G), so the blocks of an image start after the
-// image's producer (x == 0) has: a consumer only ever waits for a block that is already resident -- no assumption about dispatch order.
-//   producer: the bracket [ka, kb] from the 4096 sample keys (step 1), published with a release fence + flag;
-//   every block (the producer too): streams its share of the image (step 2) -- its first loads are in flight BEFORE it waits for the
-//     flag -- wave by wave, no block-level barrier: a wave's candidates go to the list behind one atomic per wave and step, its
-//     below-bracket and NaN counts are summed in registers and added once at the end;
-//   the LAST block of the image to finish (second counter) runs the exact select on the candidates (step 3) and re-zeroes the image's
-//     header; the last image to finish re-zeroes the ticket counter.  `work` is therefore all-zero between launches (the codec zeroes
-//     it once, when it allocates it).  With many images in flight the sample phase of one image runs beside the streaming of others.
-// work: [0] ticket counter, [1] images done; image b at 8 + b * PC_QW_STRIDE: nan count, candidate count, ka, kb, less, bracket flag,
-// blocks done, pad, then PC_QW_CAP candidates (positions independent of B: a buffer reused with another B keeps its zero headers).
-#define PC_QW_GLOBAL 8
-template <bool VEC>
-__global__ __launch_bounds__(256) void quantile_onepass_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q, float* __restrict__ thr,
-                                                               int64_t sb, uint32_t* __restrict__ work, int B, int G)
+__global__ __launch_bounds__(256) void quantile_sample_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q, int64_t sb,
+                                                             uint32_t* __restrict__ work)
 {
     __shared__ uint32_t hist[4096];
-    __shared__ uint32_t sh[8];
-    const int tid = threadIdx.x, lane = tid & 63;
-    if (tid == 0) sh[4] = atomicAdd(&work[0], 1u);
-    __syncthreads();
-    const uint32_t ticket = sh[4];
-    const int b = (int)(ticket / (uint32_t)G), x = (int)(ticket % (uint32_t)G);
-    uint32_t* w = work + PC_QW_GLOBAL + (size_t)b * PC_QW_STRIDE;
+    __shared__ uint32_t sh[4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int64_t n = (int64_t)HW * C;
+    const float* base = scale + (int64_t)b * sb;
+    const int64_t start = (int64_t)tid * ((n - 16) / 255);
+    uint32_t k[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t e = start + i, p = e / C;
+        k[i] = fkey(base[p * ld + (e - p * C)]);
+    }
+    // sample ranks around q * (m - 1): margin = 7 standard deviations of a binomial sample quantile (the runs of 16 are correlated,
+    // so count on half the nominal sample size) + 8
+    const float m1 = (float)(PC_QW_M - 1);
+    const float c = q * m1, sd = sqrtf(fmaxf(q * (1.0f - q), 0.0f) * (float)PC_QW_M);
+    const float mg = 7.0f * sd + 8.0f;
+    const float fa = floorf(c - mg), fb = ceilf(c + mg);
+    uint32_t ka = 0u, kb = 0xffffffffu;
+    if (fa > 0.0f) ka = sample_prefix(k, (uint32_t)fa, hist, sh) << 12;
+    if (fb < m1) kb = (sample_prefix(k, (uint32_t)fb, hist, sh) << 12) | 0xfffu;
+    if (tid == 0) {
+        uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+        w[0] = 0; w[1] = 0; w[2] = ka; w[3] = kb; w[4] = 0;
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void quantile_bracket_kernel(const float* __restrict__ scale, int ld, int HW, int C, int64_t sb,
+                                                              uint32_t* __restrict__ work)
+{
+    __shared__ uint32_t sh_take[4], sh_less[4], sh_nan[4], sh_base;
+    const int b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+    const uint32_t ka = w[2], kb = w[3];
     uint32_t* cand = w + PC_QW_HDR;
     const int64_t n = (int64_t)HW * C;
     const float* base = scale + (int64_t)b * sb;
-
-    auto load_step = [&](int64_t e0, uint32_t (&k)[16], uint32_t& inmask) {     // 4 K elements per step: thread t owns e0 + 4 (t + 256 i) .. + 3
-        inmask = 0u;
+    // 4 K elements per step: thread t owns elements e0 + 4 * (t + 256 * i) .. + 3, i < 4; all 16-byte loads in flight before the first use
+    for (int64_t e0 = (int64_t)blockIdx.x * PC_QW_STEP; e0 < n; e0 += (int64_t)gridDim.x * PC_QW_STEP) {
+        uint32_t k[16];
+        bool in[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t e = e0 + 4 * (tid + 256 * (int64_t)i);
             if (VEC) {
                 const int64_t p = e / C;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < n) { v = *reinterpret_cast<const float4*>(base + p * ld + (e - p * C)); inmask |= 0xfu << (4 * i); }   // n % 4 == 0: whole quad or nothing
+                if (e < n) v = *reinterpret_cast<const float4*>(base + p * ld + (e - p * C));    // n % 4 == 0: whole quad or nothing
                 k[4 * i] = fkey(v.x); k[4 * i + 1] = fkey(v.y); k[4 * i + 2] = fkey(v.z); k[4 * i + 3] = fkey(v.w);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) in[4 * i + j] = e < n;
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int64_t ee = e + j, p = ee / C;
-                    k[4 * i + j] = 0u;
-                    if (ee < n) { k[4 * i + j] = fkey(base[p * ld + (ee - p * C)]); inmask |= 1u << (4 * i + j); }
+                    in[4 * i + j] = ee < n;
+                    k[4 * i + j] = in[4 * i + j] ? fkey(base[p * ld + (ee - p * C)]) : 0u;
                 }
             }
         }
-    };
-    uint32_t k[16], inmask;
-    int64_t e0 = (int64_t)x * PC_QW_STEP;
-    uint32_t ka = 0u, kb = 0xffffffffu;
-    if (x == 0) {
-        // ---- step 1 (this image's producer): the bracket from 256 runs of 16 consecutive sample keys
-        const int64_t start = (int64_t)tid * ((n - 16) / 255);
-        uint32_t ks[16];
+        uint32_t take = 0, less = 0, nan = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const int64_t e = start + i, p = e / C;
-            ks[i] = fkey(base[p * ld + (e - p * C)]);
-        }
-        const float m1 = (float)(PC_QW_M - 1);
-        const float c = q * m1, sd = sqrtf(fmaxf(q * (1.0f - q), 0.0f) * (float)PC_QW_M);
-        const float mg = 7.0f * sd + 8.0f;
-        const float fa = floorf(c - mg), fb = ceilf(c + mg);
-        if (fa > 0.0f) ka = sample_prefix(ks, (uint32_t)fa, hist, sh) << 12;
-        if (fb < m1) kb = (sample_prefix(ks, (uint32_t)fb, hist, sh) << 12) | 0xfffu;
-        if (tid == 0) {
-            __hip_atomic_store(&w[2], ka, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&w[3], kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&w[5], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (e0 < n) load_step(e0, k, inmask);
-    } else {
-        if (e0 < n) load_step(e0, k, inmask);                          // in flight while the bracket is waited for
-        if (tid == 0) {
-            // spin on a RELAXED device-scope load and fence once the flag is up: an acquire load per iteration is a cache invalidate per
-            // iteration (1800 spinning blocks took the launch from ~40 us to 380 us)
-            while (__hip_atomic_load(&w[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(8);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            sh[5] = __hip_atomic_load(&w[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            sh[6] = __hip_atomic_load(&w[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        ka = sh[5]; kb = sh[6];
-    }
-    // ---- step 2: stream, wave by wave
-    uint32_t less_acc = 0, nan_acc = 0;
-    for (; e0 < n; e0 += (int64_t)G * PC_QW_STEP) {
-        uint32_t take = 0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const bool in = (inmask >> i) & 1u;
-            take += in && k[i] >= ka && k[i] <= kb;
-            less_acc += in && k[i] < ka;
-            nan_acc += in && (k[i] > 0xff800000u || k[i] < 0x007fffffu);    // keys of +NaN lie above +inf's, of -NaN below -inf's
+            take += in[i] && k[i] >= ka && k[i] <= kb;
+            less += in[i] && k[i] < ka;
+            nan += in[i] && (k[i] > 0xff800000u || k[i] < 0x007fffffu);      // keys of +NaN lie above +inf's, of -NaN below -inf's
         }
         uint32_t incl = take;
         for (int off = 1; off < 64; off <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, off); if (lane >= off) incl += o; }
-        const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-        if (total) {                                                      // wave-uniform
-            uint32_t pos = 0;
-            if (lane == 63) pos = atomicAdd(&w[1], total);
-            pos = (uint32_t)__shfl((int)pos, 63) + incl - take;
-#pragma unroll
-            for (int i = 0; i < 16; ++i)
-                if (((inmask >> i) & 1u) && k[i] >= ka && k[i] <= kb) { if (pos < PC_QW_CAP) cand[pos] = k[i]; pos++; }
+        for (int off = 32; off; off >>= 1) { less += (uint32_t)__shfl_xor((int)less, off); nan += (uint32_t)__shfl_xor((int)nan, off); }
+        if (lane == 63) sh_take[wv] = incl;
+        if (lane == 0) { sh_less[wv] = less; sh_nan[wv] = nan; }
+        __syncthreads();
+        if (tid == 0) {
+            const uint32_t tt = sh_take[0] + sh_take[1] + sh_take[2] + sh_take[3];
+            const uint32_t tl = sh_less[0] + sh_less[1] + sh_less[2] + sh_less[3], tn = sh_nan[0] + sh_nan[1] + sh_nan[2] + sh_nan[3];
+            sh_base = tt ? atomicAdd(&w[1], tt) : 0u;
+            if (tl) atomicAdd(&w[4], tl);
+            if (tn) atomicAdd(&w[0], tn);
         }
-        const int64_t en = e0 + (int64_t)G * PC_QW_STEP;
-        if (en < n) load_step(en, k, inmask);
+        uint32_t before = 0;
+        for (int i = 0; i < wv; ++i) before += sh_take[i];
+        __syncthreads();
+        uint32_t pos = sh_base + before + incl - take;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            if (in[i] && k[i] >= ka && k[i] <= kb) { if (pos < PC_QW_CAP) cand[pos] = k[i]; pos++; }
+        }
+        __syncthreads();
     }
-    for (int off = 32; off; off >>= 1) { less_acc += (uint32_t)__shfl_xor((int)less_acc, off); nan_acc += (uint32_t)__shfl_xor((int)nan_acc, off); }
-    if (lane == 0) { if (less_acc) atomicAdd(&w[4], less_acc); if (nan_acc) atomicAdd(&w[0], nan_acc); }
-    // ---- step 3: the last block of the image selects
-    // every WAVE makes its own candidate stores and counter atomics visible device-wide before the block signals: the release of
-    // thread 0's counter increment below covers thread 0's wave only (a barrier orders issue, not completion at the L2 -- without this
-    // fence the last block could read counters that other waves' atomics had not reached yet, and took the fallback select)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
-    if (tid == 0) sh[7] = __hip_atomic_fetch_add(&w[6], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (sh[7] != (uint32_t)(G - 1)) return;
-    __threadfence();
-    const uint32_t cnt = __hip_atomic_load(&w[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), less = __hip_atomic_load(&w[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t nan0 = __hip_atomic_load(&w[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(1024) void quantile_final_kernel(const float* __restrict__ scale, int ld, int HW, int C, float q,
+                                                             float* __restrict__ thr, int64_t sb, const uint32_t* __restrict__ work)
+{
+    const int b = blockIdx.x;
+    const uint32_t* w = work + (size_t)b * PC_QW_STRIDE;
+    const int64_t n = (int64_t)HW * C;
+    const uint32_t cnt = w[1], less = w[4];
     const float rank = q * (float)(n - 1);
     const uint32_t lo = (uint32_t)floorf(rank), hi = (uint32_t)ceilf(rank);
     const bool ok = less <= lo && hi < less + cnt;
-    if (ok && cnt <= 8192) quantile_block<32, true, 256>(nullptr, 0, 1, cand, cnt, n, less, nan0, q, thr + b);
-    else if (ok && cnt <= PC_QW_CAP) quantile_block<0, true, 256>(nullptr, 0, 1, cand, cnt, n, less, nan0, q, thr + b);
-    else quantile_block<0, false, 256>(base, ld, C, nullptr, n, n, 0u, 0u, q, thr + b);
-    __syncthreads();
-    if (tid < PC_QW_HDR) w[tid] = 0u;                                     // the header is zero again for the next launch
-    if (tid == 0) {
-        if (__hip_atomic_fetch_add(&work[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (uint32_t)(B - 1)) { work[0] = 0u; work[1] = 0u; }
-    }
+    if (ok && cnt <= 8192) quantile_block<8, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, less, w[0], q, thr + b);
+    else if (ok && cnt <= PC_QW_CAP) quantile_block<32, true>(nullptr, 0, 1, w + PC_QW_HDR, cnt, n, less, w[0], q, thr + b);
+    else quantile_block<0, false>(scale + (int64_t)b * sb, ld, C, nullptr, n, n, 0u, 0u, q, thr + b);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -857,35 +831,6 @@ int pc_eb_likelihood_launch(const int32_t* sym, int B, int HW, int C, const floa
     return PC_LAUNCH_CHECK();
 }
 
-namespace {
-// scratch of the stand-alone entry point (pc_mask_quantile_threshold): one zero-initialised buffer per (device, stream), grown on demand
-uint32_t* standalone_quantile_work(int B, hipStream_t stream)
-{
-    struct Slot { int dev; hipStream_t st; uint32_t* p; size_t bytes; };
-    static std::mutex mu;
-    static std::vector<Slot> slots;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const size_t need = pc_quantile_work_bytes(B);
-    std::lock_guard<std::mutex> lk(mu);
-    for (auto& s : slots)
-        if (s.dev == dev && s.st == stream) {
-            if (s.bytes >= need) return s.p;
-            (void)hipStreamSynchronize(stream);
-            (void)hipFree(s.p);
-            s.p = nullptr; s.bytes = 0;
-            if (hipMalloc(reinterpret_cast<void**>(&s.p), need) != hipSuccess || hipMemset(s.p, 0, need) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { s.p = nullptr; return nullptr; }
-            s.bytes = need;
-            return s.p;
-        }
-    Slot s{dev, stream, nullptr, 0};
-    if (hipMalloc(reinterpret_cast<void**>(&s.p), need) != hipSuccess || hipMemset(s.p, 0, need) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) return nullptr;
-    s.bytes = need;
-    slots.push_back(s);
-    return s.p;
-}
-}  // namespace
-
 int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, float q, float* thr, uint32_t* work, hipStream_t stream, int64_t sb)
 {
     if (B <= 0 || HW <= 0 || C <= 0) return PC_ERR_ARG;
@@ -896,22 +841,19 @@ int pc_quantile_thr_launch(const float* scale, int ld, int B, int HW, int C, flo
     else if (n <= PC_QUANTILE_SMALL_N) hipLaunchKernelGGL(quantile_thr_kernel<32>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else if (single) hipLaunchKernelGGL(quantile_thr_kernel<0>, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb);
     else {
-        // one launch (quantile_onepass_kernel): `work` must be all-zero between launches -- the kernel leaves it so; the codec zeroes its
-        // buffer when it allocates it, the stand-alone entry point keeps one zeroed buffer per (device, stream)
-        uint32_t* w = work ? work : standalone_quantile_work(B, stream);
-        if (!w) return PC_ERR_HIP;
-        // blocks per image: enough 16-KB steps in flight to cover the HBM latency (~2048 blocks over the launch), at least two steps per
-        // block where the image allows (the producer's sample phase and every block's ticket are amortised over them)
-        const int64_t steps = (n + PC_QW_STEP - 1) / PC_QW_STEP;
-        int G = (int)std::min<int64_t>(std::max<int64_t>(1, 2048 / B), std::max<int64_t>(1, steps / 2));
-        G = std::min(G, 256);
+        uint32_t* w = work;
+        if (!w && hipMallocAsync(reinterpret_cast<void**>(&w), pc_quantile_work_bytes(B), stream) != hipSuccess) return PC_ERR_HIP;
+        const int G = (int)std::min<int64_t>(256, (n + PC_QW_STEP - 1) / PC_QW_STEP);
         const bool vec = !(C & 3) && !(ld & 3) && !(sb & 3) && !(reinterpret_cast<uintptr_t>(scale) & 15u);
-        if (vec) hipLaunchKernelGGL(quantile_onepass_kernel<true>, dim3((unsigned)G * (unsigned)B), dim3(256), 0, stream, scale, ld, HW, C, q, thr, sb, w, B, G);
-        else hipLaunchKernelGGL(quantile_onepass_kernel<false>, dim3((unsigned)G * (unsigned)B), dim3(256), 0, stream, scale, ld, HW, C, q, thr, sb, w, B, G);
+        hipLaunchKernelGGL(quantile_sample_kernel, dim3(B), dim3(256), 0, stream, scale, ld, HW, C, q, sb, w);
+        if (vec) hipLaunchKernelGGL(quantile_bracket_kernel<true>, dim3(G, B), dim3(256), 0, stream, scale, ld, HW, C, sb, w);
+        else hipLaunchKernelGGL(quantile_bracket_kernel<false>, dim3(G, B), dim3(256), 0, stream, scale, ld, HW, C, sb, w);
+        hipLaunchKernelGGL(quantile_final_kernel, dim3(B), dim3(1024), 0, stream, scale, ld, HW, C, q, thr, sb, (const uint32_t*)w);
+        if (!work && hipFreeAsync(w, stream) != hipSuccess) return PC_ERR_HIP;
     }
     return PC_LAUNCH_CHECK();
 }
-size_t pc_quantile_work_bytes(int B) { return ((size_t)PC_QW_GLOBAL + (size_t)B * PC_QW_STRIDE) * sizeof(uint32_t); }
+size_t pc_quantile_work_bytes(int B) { return (size_t)B * PC_QW_STRIDE * sizeof(uint32_t); }
 
 int pc_prep_enc_launch(const pc_prep_params& p, hipStream_t stream)
 {

@@ -308,10 +308,9 @@ def test_gc_prep_encode_and_decode_bit_exact(hw, mode, delta):
     assert np.array_equal(yhat2.cpu().numpy().view(np.uint32), yhat_w.view(np.uint32))
 
 
-def test_quantile_one_launch_repeated_calls_and_changing_batch():
-    """The one-launch quantile (quantile_onepass_kernel) keeps its scratch all-zero between launches: the same stream's buffer is used by
-    calls of different batch and image sizes, back to back with no host synchronisation in between, and every threshold must still be
-    the exact order statistic (a header left non-zero, or a ticket counter not rewound, would show as a wrong or hanging later call)."""
+def test_quantile_repeated_calls_and_changing_batch():
+    """Calls of different batch and image sizes back to back on one stream with no host synchronisation in between (the large-image path
+    reuses its scratch: candidate lists, counters): every threshold must still be the exact order statistic."""
     L, check = _lib()
     rng = np.random.default_rng(77)
     cases = [(3, 4096, 0.5), (1, 5000, 2.0), (7, 2048, 9.0), (2, 70000, 0.05), (5, 1500, 5.0), (3, 4096, 0.5), (1, 65281, 1.0), (16, 1100, 3.0), (4, 4096, 7.5)]

@@ -17,6 +17,9 @@ from progressivecodec_amd import ChannelProgresssiveWACNN, synth
 from progressivecodec_amd.harness import PR_LIST, compute_padding
 
 
+SPLIT = {}
+
+
 def timed(fn, reps):
     fn()
     torch.cuda.synchronize()
@@ -25,6 +28,19 @@ def timed(fn, reps):
         fn()
     torch.cuda.synchronize()
     return (time.time() - t0) / reps
+
+
+def split(name, enc, dec, reps):
+    """encode and decode timed apart (a synchronisation between them: what the joint figure of `timed` does not pay)"""
+    out = enc()
+    dec(out)
+    torch.cuda.synchronize()
+    te = td = 0.0
+    for _ in range(reps):
+        t0 = time.time(); out = enc(); torch.cuda.synchronize(); t1 = time.time()
+        dec(out); torch.cuda.synchronize(); t2 = time.time()
+        te += t1 - t0; td += t2 - t1
+    SPLIT[name] = {"encode_s": round(te / reps, 4), "decode_s": round(td / reps, 4)}
 
 
 def main():
@@ -47,7 +63,8 @@ def main():
     def c3():
         ds = net.compress_levels(x, levels, pol)
         net.decompress_levels([d["strings"] for d in ds], ds[0]["shape"], levels, pol)
-    report("Config 3", "8 images of 512x768, 13 levels, compress_levels + decompress_levels", 8 * 512 * 768 * 13 / 1e6, timed(c3, reps), {})
+    split("c3", lambda: net.compress_levels(x, levels, pol), lambda ds: net.decompress_levels([d["strings"] for d in ds], ds[0]["shape"], levels, pol), reps)
+    report("Config 3", "8 images of 512x768, 13 levels, compress_levels + decompress_levels", 8 * 512 * 768 * 13 / 1e6, timed(c3, reps), SPLIT["c3"])
     del x
 
     # Config 4 (per-GPU shard)
@@ -72,8 +89,9 @@ def main():
     def c5():
         ds = net.compress_levels(xp, lv8, pol)
         net.decompress_levels([d["strings"] for d in ds], ds[0]["shape"], lv8, pol)
+    split("c5", lambda: net.compress_levels(xp, lv8, pol), lambda ds: net.decompress_levels([d["strings"] for d in ds], ds[0]["shape"], lv8, pol), reps)
     report("Config 5 (one frame per rank)", "one 3840x2160 frame (padded to 3840x2176), 8 levels, compress_levels + decompress_levels",
-           2160 * 3840 * 8 / 1e6, timed(c5, reps), {})
+           2160 * 3840 * 8 / 1e6, timed(c5, reps), SPLIT["c5"])
 
 
 if __name__ == "__main__":

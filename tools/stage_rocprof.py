@@ -10,7 +10,7 @@ GB/s they make at the trace's duration, next to the algorithmic figure (VERDICT 
 
 stage_bench.py calls, in this order: the quantile once, then (1 + 10) times each of: quantile, encoder enhancement prep, encoder base
 prep, decoder index, dequantise.  The kernel trace is cut into those calls by start time; a call of the quantile on a Config-4 slice
-was three kernels (sample / bracket / final) until round 3 and is one (quantile_onepass_kernel) since round 4; every other call is one kernel;
+is three kernels (sample / bracket / final; a one-launch form was built and rejected in round 4, pc_stages.hip); every other call is one kernel;
 the per-kernel averages are reported too."""
 import csv
 import glob
