@@ -290,6 +290,11 @@ PC_API int pc_codec_profile_intervals(const pc_codec* c, double* t0_ms, double* 
  * decoded by those calls.  n >= 6. */
 PC_API int pc_codec_host_stats(const pc_codec* c, double* out, int n);
 
+/* Test aid: the conv epilogue evaluates GELU (layers/layers.py:45, nn.GELU) on two elements per lane with packed f32 instructions; this
+ * compares that form with the contract's scalar pc_geluf (include/pc_math.h) over ALL 2^32 float arguments on the current device.
+ * *n_mismatch must be 0; *n_nan_payload counts arguments for which both forms return NaN with different payload bits.  Synchronous. */
+PC_API int pc_selftest_packed_gelu(uint64_t* n_mismatch, uint64_t* n_nan_payload);
+
 /* Debug/test taps: copy an internal device tensor of the last call to host ("y", "z", "latent_means", ...). */
 PC_API int pc_codec_read_tap(pc_codec* c, const char* name, float* host_out, size_t cap_floats, size_t* n_floats);
 PC_API int pc_codec_read_tap_i32(pc_codec* c, const char* name, int32_t* host_out, size_t cap, size_t* n);

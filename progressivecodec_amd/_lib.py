@@ -21,7 +21,7 @@ EXPORTS = [
     "pc_codec_profile_begin", "pc_codec_profile_end", "pc_codec_compress_levels", "pc_codec_get_level_string",
     "pc_codec_decompress_levels", "pc_codec_forward", "pc_codec_set_cust_map", "pc_codec_strings_size", "pc_codec_copy_strings",
     "pc_codec_decompress_packed", "pc_host_pool_plan", "pc_rans_decode_stream", "pc_codec_set_scale_table", "pc_codec_profile_bytes", "pc_contract_id", "pc_rans_decode_batch_u8", "pc_codec_set_rem",
-    "pc_codec_host_stats", "pc_codec_set_rem_checkpoint", "pc_codec_set_option", "pc_profile_set_epoch", "pc_codec_profile_intervals",
+    "pc_codec_host_stats", "pc_codec_set_rem_checkpoint", "pc_codec_set_option", "pc_selftest_packed_gelu", "pc_profile_set_epoch", "pc_codec_profile_intervals",
 ]
 
 
@@ -77,6 +77,8 @@ def lib():
         L.pc_codec_finalize.argtypes = [vp]
         L.pc_codec_set_threads.argtypes = [vp, C.c_int]
         L.pc_codec_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+        if hasattr(L, "pc_selftest_packed_gelu"):           # (absent from older builds selected with PC_LIB for a same-box A/B)
+            L.pc_selftest_packed_gelu.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.pc_codec_compress.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, vp, vp]
         L.pc_codec_num_slices.argtypes = [vp]
         L.pc_codec_get_string.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.POINTER(sz)]

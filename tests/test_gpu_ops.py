@@ -325,3 +325,13 @@ def test_quantile_repeated_calls_and_changing_batch():
     for (B, hw, pr), sc, thr in zip(cases, scales, outs):
         want = np.array([lo.quantile(sc[b], np.float32(1.0 - pr * 0.1)) for b in range(B)], np.float32)
         assert np.array_equal(thr.cpu().numpy().view(np.uint32), want.view(np.uint32)), (B, hw, pr)
+
+
+def test_packed_gelu_equals_the_contract_function_on_every_float():
+    """The epilogue's two-elements-per-lane GELU (v_pk_fma_f32 ...; pc_conv.hip: pc_geluf2) against include/pc_math.h: pc_geluf over all
+    2^32 arguments: not one differing bit (NaN payloads aside) -- the numeric contract id stays 0x00020001."""
+    L, check = _lib()
+    bad, nanp = C.c_uint64(), C.c_uint64()
+    check(L.pc_selftest_packed_gelu(C.byref(bad), C.byref(nanp)))
+    print("packed GELU vs pc_geluf over 2^32 arguments: mismatches", bad.value, "NaN results with another payload", nanp.value)
+    assert bad.value == 0
