@@ -319,7 +319,7 @@ int load_wam(pc_codec* c, const std::string& p, int C, int ws, int shift, WamW* 
     const HostTensor* tab = find(c, p + ".conv_b.0.attn.relative_position_bias_table", PC_F32, {R, HEADS});
     const HostTensor* idx = find(c, p + ".conv_b.0.attn.relative_position_index", PC_I64, {T, T});
     if (!tab || !idx) { std::fprintf(stderr, "[pcodec] missing attention tables %s\n", p.c_str()); return PC_ERR_MISSING; }
-    // dense bias[h][i][j] = table[index[i][j]][h]   (win_attention.py:97-100)
+    // dense bias, stored TRANSPOSED: bias[h][j][i] = table[index[i][j]][h]   (win_attention.py:97-100; [j][i]: coalesced across the query lanes)
     std::vector<float> dense((size_t)HEADS * T * T);
     const float* t = reinterpret_cast<const float*>(tab->data.data());
     const int64_t* ix = reinterpret_cast<const int64_t*>(idx->data.data());
@@ -327,7 +327,7 @@ int load_wam(pc_codec* c, const std::string& p, int C, int ws, int shift, WamW* 
         for (int j = 0; j < T; ++j) {
             const int64_t r = ix[(size_t)i * T + j];
             if (r < 0 || r >= R) return PC_ERR_MISSING;
-            for (int h = 0; h < HEADS; ++h) dense[((size_t)h * T + i) * T + j] = t[r * HEADS + h];
+            for (int h = 0; h < HEADS; ++h) dense[((size_t)h * T + j) * T + i] = t[r * HEADS + h];
         }
     PCCHK(upload(c, dense, &w->bias));
     return PC_OK;
@@ -475,7 +475,7 @@ int wam(pc_codec* c, hipStream_t st, const WamW& w, const float* x, int B, int H
     PCCHK(ru(st, w.a[2], a1, C, B, H, W, t1, t2, a0));                  // a in a0
     // branch b: window attention, three residual units, 1x1
     PCCHK(conv(st, w.qkv, {{x, C, C}}, B, H, W, 1, qkv, 3 * C, PC_EPI_NONE));
-    PCCHK(pc_win_attention_launch(qkv, w.bias, B, H, W, C, HEADS, w.ws, w.shift, (float)std::pow((double)(C / HEADS), -0.5), a1, st));
+    PCCHK(pc_win_attention_launch(qkv, w.bias, B, H, W, C, HEADS, w.ws, w.shift, (float)std::pow((double)(C / HEADS), -0.5), a1, st, 1));
     PCCHK(conv(st, w.proj, {{a1, C, C}}, B, H, W, 1, o, C, PC_EPI_RES, x, C));     // shortcut + proj(attn)
     PCCHK(ru(st, w.b[0], o, C, B, H, W, t1, t2, b1));
     PCCHK(ru(st, w.b[1], b1, C, B, H, W, t1, t2, o));

@@ -104,8 +104,10 @@ size_t pc_rowtab_cache_bytes(pc_rowtab_cache* c);
 int pc_conv_weight_layout(int kind, int Cin, int Cout, int k);
 
 // window attention core
+// bias: dense relative-position bias, [heads][T][T] as bias[h][i][j] (bias_ji = 0: the module's order, win_attention.py:97-100) or
+// transposed bias[h][j][i] (bias_ji = 1: what the codec stores -- coalesced across the query lanes)
 int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int ws,
-                            int shift, float scale, float* out, hipStream_t stream);
+                            int shift, float scale, float* out, hipStream_t stream, int bias_ji = 0);
 
 // entropy-parameter stages
 struct pc_prep_params {

@@ -19,10 +19,12 @@ namespace {
 // s_j = fmaf-chain_e (q[e]*scale) * k_j[e];  += bias;  += shift mask;  softmax;  o[e] = fmaf-chain_j p_j v_j[e]
 // (same chains as oracle/pc_oracle.c:orc_win_attention)
 // ------------------------------------------------------------------------------------------
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+
 template <int WS, int D>
 __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ bias,
                                                             int B, int H, int W, int C, int heads, int shift, float scale,
-                                                            float* __restrict__ out, int npairs)
+                                                            float* __restrict__ out, int npairs, int bias_ji)
 {
     constexpr int T = WS * WS, G = 64 / T;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -46,10 +48,14 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
     // G == 1 (8x8 windows): the wave's 64 lanes are the 64 tokens of ONE (window, head) pair.  Every lane needs every token's k and
     // v: staged once in LDS (each lane writes its own token's two vectors) and read back as broadcasts, instead of 2 x 64 x D/4
     // same-address vector loads per lane from L1.  Same fmaf chains, same results.
+    // Round 4: on the G == 1 path the two fmaf loops run on PACKED f32 instructions (v_pk_fma_f32: two independent chains per instruction
+    // -- scores of two neighbouring keys j, j+1 in QK^T; outputs of two neighbouring channels e, e+1 in PV).  Per component the same fmaf
+    // on the same operands in the same order: the bits do not move (the bit-exact suites are the check).  For the key pairs K sits in LDS
+    // TRANSPOSED ([e][j]: a broadcast float4 read gives four consecutive keys of one channel); V stays [j][e].
     constexpr int LDK = D + 4;                                 // padded row: 16-byte aligned, spreads the banks
-    __shared__ float kv_lds[G == 1 ? 4 * 2 * T * LDK : 1];
-    float* k_lds = kv_lds + (G == 1 ? wave * 2 * T * LDK : 0);
-    float* v_lds = k_lds + (G == 1 ? T * LDK : 0);
+    __shared__ float kv_lds[G == 1 ? 4 * (T * D + T * LDK) : 1];
+    float* k_lds = kv_lds + (G == 1 ? wave * (T * D + T * LDK) : 0);     // G == 1: [D][T]
+    float* v_lds = k_lds + (G == 1 ? T * D : 0);                          //         [T][LDK]
 
     int reg_i;
     const int64_t pix_i = token(i, reg_i);
@@ -58,7 +64,8 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
         const float4* vp = reinterpret_cast<const float4*>(qkv + pix_i * C3 + 2 * C + h * D);
 #pragma unroll
         for (int e = 0; e < D / 4; ++e) {
-            *reinterpret_cast<float4*>(k_lds + i * LDK + 4 * e) = kp[e];
+            const float4 kk = kp[e];
+            k_lds[(4 * e + 0) * T + i] = kk.x; k_lds[(4 * e + 1) * T + i] = kk.y; k_lds[(4 * e + 2) * T + i] = kk.z; k_lds[(4 * e + 3) * T + i] = kk.w;
             *reinterpret_cast<float4*>(v_lds + i * LDK + 4 * e) = vp[e];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -74,21 +81,44 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
     }
     float s[T];
     float m = -INFINITY;
+    if (G == 1) {
+        // all T chains advance together, channel by channel (each chain still visits e = 0, 1, ... in order), two keys per instruction
+        f32x2v s2[T / 2];
+#pragma unroll
+        for (int j = 0; j < T / 2; ++j) s2[j] = f32x2v{0.0f, 0.0f};
+#pragma unroll
+        for (int e = 0; e < D; ++e) {
+            const f32x2v qe = {q[e], q[e]};
+#pragma unroll
+            for (int jq = 0; jq < T / 4; ++jq) {
+                const float4 kk = *reinterpret_cast<const float4*>(k_lds + e * T + 4 * jq);
+                s2[2 * jq] = __builtin_elementwise_fma(qe, f32x2v{kk.x, kk.y}, s2[2 * jq]);
+                s2[2 * jq + 1] = __builtin_elementwise_fma(qe, f32x2v{kk.z, kk.w}, s2[2 * jq + 1]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < T / 2; ++j) { s[2 * j] = s2[j].x; s[2 * j + 1] = s2[j].y; }
+    }
 #pragma unroll
     for (int j = 0; j < T; ++j) {
         int reg_j;
         const int64_t pix_j = token(j, reg_j);
-        const float4* kp = G == 1 ? reinterpret_cast<const float4*>(k_lds + j * LDK) : reinterpret_cast<const float4*>(qkv + pix_j * C3 + C + h * D);
         float acc = 0.0f;
+        if (G == 1) acc = s[j];
+        else {
+            const float4* kp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + C + h * D);
 #pragma unroll
-        for (int e = 0; e < D / 4; ++e) {
-            const float4 k = kp[e];
-            acc = fmaf(q[4 * e + 0], k.x, acc);
-            acc = fmaf(q[4 * e + 1], k.y, acc);
-            acc = fmaf(q[4 * e + 2], k.z, acc);
-            acc = fmaf(q[4 * e + 3], k.w, acc);
+            for (int e = 0; e < D / 4; ++e) {
+                const float4 k = kp[e];
+                acc = fmaf(q[4 * e + 0], k.x, acc);
+                acc = fmaf(q[4 * e + 1], k.y, acc);
+                acc = fmaf(q[4 * e + 2], k.z, acc);
+                acc = fmaf(q[4 * e + 3], k.w, acc);
+            }
         }
-        acc = acc + bias[((int64_t)h * T + i) * T + j];
+        // bias_ji: the table is stored [head][j][i] -- for a fixed key j the wave's 64 query lanes read 64 consecutive floats (one 256-byte
+        // request); in the module's own [head][i][j] order every lane reads its own row and a load instruction touches 64 cache lines
+        acc = acc + (bias_ji ? bias[((int64_t)h * T + j) * T + i] : bias[((int64_t)h * T + i) * T + j]);
         if (shift > 0) acc = acc + (reg_i != reg_j ? -100.0f : 0.0f);
         s[j] = acc;
         m = acc > m ? acc : m;
@@ -101,18 +131,37 @@ __global__ __launch_bounds__(256) void win_attention_kernel(const float* __restr
     float o[D];
 #pragma unroll
     for (int e = 0; e < D; ++e) o[e] = 0.0f;
+    if (G == 1) {
+        f32x2v o2[D / 2];
 #pragma unroll
-    for (int j = 0; j < T; ++j) {
-        int reg_j;
-        const int64_t pix_j = token(j, reg_j);
-        const float4* vp = G == 1 ? reinterpret_cast<const float4*>(v_lds + j * LDK) : reinterpret_cast<const float4*>(qkv + pix_j * C3 + 2 * C + h * D);
+        for (int e = 0; e < D / 2; ++e) o2[e] = f32x2v{0.0f, 0.0f};
 #pragma unroll
-        for (int e = 0; e < D / 4; ++e) {
-            const float4 v = vp[e];
-            o[4 * e + 0] = fmaf(s[j], v.x, o[4 * e + 0]);
-            o[4 * e + 1] = fmaf(s[j], v.y, o[4 * e + 1]);
-            o[4 * e + 2] = fmaf(s[j], v.z, o[4 * e + 2]);
-            o[4 * e + 3] = fmaf(s[j], v.w, o[4 * e + 3]);
+        for (int j = 0; j < T; ++j) {
+            const f32x2v pj = {s[j], s[j]};
+            const float4* vp = reinterpret_cast<const float4*>(v_lds + j * LDK);
+#pragma unroll
+            for (int e = 0; e < D / 4; ++e) {
+                const float4 v = vp[e];
+                o2[2 * e] = __builtin_elementwise_fma(pj, f32x2v{v.x, v.y}, o2[2 * e]);
+                o2[2 * e + 1] = __builtin_elementwise_fma(pj, f32x2v{v.z, v.w}, o2[2 * e + 1]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < D / 2; ++e) { o[2 * e] = o2[e].x; o[2 * e + 1] = o2[e].y; }
+    } else {
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+            int reg_j;
+            const int64_t pix_j = token(j, reg_j);
+            const float4* vp = reinterpret_cast<const float4*>(qkv + pix_j * C3 + 2 * C + h * D);
+#pragma unroll
+            for (int e = 0; e < D / 4; ++e) {
+                const float4 v = vp[e];
+                o[4 * e + 0] = fmaf(s[j], v.x, o[4 * e + 0]);
+                o[4 * e + 1] = fmaf(s[j], v.y, o[4 * e + 1]);
+                o[4 * e + 2] = fmaf(s[j], v.z, o[4 * e + 2]);
+                o[4 * e + 3] = fmaf(s[j], v.w, o[4 * e + 3]);
+            }
         }
     }
     float4* op = reinterpret_cast<float4*>(out + pix_i * C + h * D);
@@ -761,7 +810,7 @@ __global__ void nchw_slice_to_nhwc_kernel(const float* __restrict__ src, int64_t
 #define PC_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP)
 
 int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, int W, int C, int heads, int ws,
-                            int shift, float scale, float* out, hipStream_t stream)
+                            int shift, float scale, float* out, hipStream_t stream, int bias_ji)
 {
     if (heads <= 0 || C % heads || H % ws || W % ws || shift < 0 || shift >= ws) return PC_ERR_ARG;
     const int d = C / heads, T = ws * ws;
@@ -769,11 +818,11 @@ int pc_win_attention_launch(const float* qkv, const float* bias, int B, int H, i
     const int per_block = 4 * (64 / T);
     dim3 grid((npairs + per_block - 1) / per_block), block(256);
     if (ws == 8 && d == 24)
-        hipLaunchKernelGGL((win_attention_kernel<8, 24>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+        hipLaunchKernelGGL((win_attention_kernel<8, 24>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs, bias_ji);
     else if (ws == 4 && d == 80)
-        hipLaunchKernelGGL((win_attention_kernel<4, 80>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+        hipLaunchKernelGGL((win_attention_kernel<4, 80>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs, bias_ji);
     else if (ws == 4 && d == 40)
-        hipLaunchKernelGGL((win_attention_kernel<4, 40>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs);
+        hipLaunchKernelGGL((win_attention_kernel<4, 40>), grid, block, 0, stream, qkv, bias, B, H, W, C, heads, shift, scale, out, npairs, bias_ji);
     else
         return PC_ERR_ARG;
     return PC_LAUNCH_CHECK();
