@@ -2239,7 +2239,7 @@ extern "C" int pc_codec_profile_end(pc_codec* c, int64_t* n_launches, double* to
             c->prof_rec[i / 2].t1_ms = (double)s0 + t;
         }
     }
-    if (const char* path = std::getenv("PC_PROFILE_CSV")) {      // per-launch shapes and times, for tuning
+    if (const char* path = c->profile_in_schedule ? nullptr : std::getenv("PC_PROFILE_CSV")) {      // per-launch shapes and times of the SERIAL form (in the schedule a launch's duration is not its own)
         if (FILE* f = std::fopen(path, "w")) {
             std::fprintf(f, "i,M,N,K,nphase,epi,gflop,us,tflops,alg_mbytes\n");
             for (size_t i = 0; i < c->prof_rec.size(); ++i) {
