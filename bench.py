@@ -338,7 +338,7 @@ def main():
         traffic_src = why if tj is None else "traffic profile is of the default workload only"
     alg_bytes = by.value / max(1, nl.value)
     achieved = insitu["achieved"] if insitu else lbl_achieved
-    roofline = {"bound": "mfma", "kernel": "conv_igemm_uni_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
+    roofline = {"bound": "mfma", "kernel": "conv_igemm_uni_kernel + conv_igemm_in_gdn_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4),
                 "measured_on": ("the timed schedule (CodecPipeline: encoder || decoder), second pass of the same K steps with every conv launch of both "

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // chains, the bias adds, the square and the rsqrt are those of the two-launch form (same k order, same operations): bit-identical.
 // LDS: 192 x 65 floats of x + 2 x 16 x 196 of weights = 75 008 B -> two workgroups per CU.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void conv1_gdn_fused_kernel(const pc_conv_params p)
+__global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_params p)
 {
     constexpr int BM = 64, CN = 192, BK = 16, TN = 3;
     constexpr int LDX = BM + 1, LDA = BM + 4, LDB = CN + 4;
@@ -1697,7 +1697,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
     //    loader).  (1x1 convs and GDN moved to the LDS-DMA kernel: 17-25 % faster, profiles/r01_tune_tune27.log.)
     hipError_t e;
     if (p.fg_gamma) {
-        // the input layer with its GDN fused (conv1_gdn_fused_kernel): 3 -> 192, one phase, dense NHWC output of 192 channels
+        // the input layer with its GDN fused (conv_igemm_in_gdn_kernel): 3 -> 192, one phase, dense NHWC output of 192 channels
         if (!p.smallc || p.wlayout != 0 || p.Cout != 192 || p.nphase != 1 || !p.dense_out || p.out_sc != 1 || !p.fg_beta || p.epi != PC_EPI_NONE ||
             p.ngroup == 2 || p.ntap[0] * p.Cin > 80)
             return PC_ERR_ARG;
@@ -1707,11 +1707,11 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (!(attr_set.load(std::memory_order_acquire) & (1u << (dev & 31)))) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_gdn_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_igemm_in_gdn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return PC_ERR_HIP;
             attr_set.fetch_or(1u << (dev & 31), std::memory_order_release);
         }
-        hipLaunchKernelGGL(conv1_gdn_fused_kernel, dim3((unsigned)((p.M + 63) / 64)), dim3(256), lds, stream, p);
+        hipLaunchKernelGGL(conv_igemm_in_gdn_kernel, dim3((unsigned)((p.M + 63) / 64)), dim3(256), lds, stream, p);
         return hipGetLastError() == hipSuccess ? PC_OK : PC_ERR_HIP;
     }
     if (p.wlayout == 1) {

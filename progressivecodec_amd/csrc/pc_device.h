@@ -76,7 +76,7 @@ struct pc_conv_params {
     const float* aux0; int ld0;
     const float* aux1; int ld1;
     int tile_cfg;
-    // fused GDN behind the 3-channel input layer (conv1_gdn_fused_kernel): gamma [192][192] in layout 1 (re-parametrised), beta [192];
+    // fused GDN behind the 3-channel input layer (conv_igemm_in_gdn_kernel): gamma [192][192] in layout 1 (re-parametrised), beta [192];
     // out = x * rsqrt(beta + gamma . x^2) with x = this layer's conv + bias.  Null: plain layer.
     const float* fg_gamma; const float* fg_beta;
     // grouped launch: a second GEMM of identical shape (cc_mean || cc_scale of one chain step) rides on blockIdx.z == 1;

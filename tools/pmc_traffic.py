@@ -12,7 +12,7 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-FAMILIES = [("conv_igemm_uni_kernel", "conv_igemm_uni_kernel"), ("conv_igemm_dma_kernel", "conv_igemm_dma_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
+FAMILIES = [("conv_igemm_uni_kernel", "conv_igemm_uni_kernel"), ("conv_igemm_in_gdn_kernel", "conv_igemm_in_gdn_kernel"), ("conv_igemm_dma_kernel", "conv_igemm_dma_kernel"), ("conv_igemm_kernel", "conv_igemm_kernel"),
             ("gc_prep", "gc_prep/dequant/eb"), ("gc_dequant", "gc_prep/dequant/eb"), ("eb_", "gc_prep/dequant/eb"),
             ("quantile", "quantile"), ("win_attention", "win_attention")]
 

@@ -2,7 +2,7 @@
 """Per-shape HBM-side traffic of the conv family (VERDICT r02 "Next round" 5): joins the per-dispatch `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
 counters of two serial bench passes with the per-launch shape table (PC_PROFILE_CSV) of the same kind of step.
 
-The last step a `bench.py --lean --overlap 0` process runs is the roofline-profile step: one stream, one lane, 543 conv launches in
+The last step a `bench.py --lean --overlap 0` process runs is the roofline-profile step: one stream, one lane, 542 conv launches (543 until round 3) in
 launch order -- the order of the CSV rows.  So the LAST len(csv) conv_igemm* dispatches of each PMC pass are that step's launches, row
 by row.  FETCH_SIZE (KB) is doubled as MI355X_MICROARCH.md prescribes for gfx950; both counters sit on the L2's memory side, so
 Infinity-Cache hits are included: these are L2 misses, an upper bound of the HBM bytes.
@@ -65,7 +65,7 @@ def main():
     from bench import source_hash
     print(json.dumps({"source_hash": source_hash(),
                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 1 --warmup 1 --lean --overlap 0` (serial form), "
-                                "last 543 conv dispatches = the roofline-profile step, joined by launch order with PC_PROFILE_CSV; FETCH_SIZE x2 (gfx950); "
+                                "last 542 conv dispatches = the roofline-profile step, joined by launch order with PC_PROFILE_CSV; FETCH_SIZE x2 (gfx950); "
                                 "L2 misses incl. Infinity-Cache hits",
                       "launches": n, "traffic_mb_per_launch": round(tot_tr / n, 2), "algorithmic_mb_per_launch": round(tot_alg / n, 2),
                       "traffic_over_algorithmic": round(tot_tr / tot_alg, 3),
