@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="1 (default): the decode of step i runs beside the encode of step i+1 -- an encoder and a "
                     "decoder codec object on their own streams and host threads; 0: compress() then decompress(), one after the other")
     ap.add_argument("--queue-depth", type=int, default=2, help="items the encoder may run ahead of the decoder (CodecPipeline)")
+    ap.add_argument("--pairs", type=int, default=2, help="encoder / decoder pairs of the CodecPipeline (n_pairs): 1 keeps ~2.4 conv kernels in flight, "
+                    "2 (default) ~4.5 -- each pair is two more weights copies and its workspaces")
     ap.add_argument("--serial-schedule", action="store_true", help="pc_codec_set_option serial_schedule on every codec object: one lane, one stream, no "
                     "chain pipelining inside the codec -- with --overlap 0 the form in which a launch's duration is its own (rocprofv3 / PMC passes)")
     ap.add_argument("--cpu-images", type=int, default=32, help="images of rank 0's batch the CPU port codes (x2 repetitions)")
@@ -188,14 +190,14 @@ def main():
     # streams and the decoder host thread; bench.py only feeds it jobs.  --overlap 0: one plain model object, calls in turn.
     pipe = None
     if args.overlap:
-        pipe = CodecPipeline(sd, device=str(dev), queue_depth=args.queue_depth)
+        pipe = CodecPipeline(sd, device=str(dev), queue_depth=args.queue_depth, n_pairs=args.pairs)
         net = pipe.enc
     else:
         net = ChannelProgresssiveWACNN(device=str(dev))
         net.load_state_dict(sd)
         net.update()
     if args.serial_schedule:
-        for o in ([pipe.enc, pipe.dec] if pipe else [net]):
+        for o in (pipe.objects if pipe else [net]):
             o.set_option("serial_schedule", 1)
 
     B, S, q = args.batch, args.size, args.quality
@@ -232,11 +234,18 @@ def main():
         return res
 
     log(f"weights loaded, tables built; batch {B}x3x{S}x{S} resident; warmup x{args.warmup}")
-    for i in range(args.warmup):
+    if pipe is not None and args.pairs > 1 and args.warmup > 0:
+        # the W warm-up steps as ONE pipelined run, so that every pair's objects (workspaces, row tables) are exercised before the timed region
         tw = time.perf_counter()
-        out, dec = run_steps(1)
+        out, dec = run_steps(max(args.warmup, args.pairs))
         torch.cuda.synchronize(dev)
-        log(f"warmup step {i}: {time.perf_counter() - tw:.3f} s")
+        log(f"warmup: {max(args.warmup, args.pairs)} pipelined steps over {args.pairs} pairs: {time.perf_counter() - tw:.3f} s")
+    else:
+        for i in range(args.warmup):
+            tw = time.perf_counter()
+            out, dec = run_steps(1)
+            torch.cuda.synchronize(dev)
+            log(f"warmup step {i}: {time.perf_counter() - tw:.3f} s")
     barrier()
     t0 = time.perf_counter()
     out, dec = run_steps(args.steps)
@@ -341,7 +350,7 @@ def main():
     roofline = {"bound": "mfma", "kernel": "conv_igemm_uni_kernel + conv_igemm_in_gdn_kernel + conv_igemm_kernel (f32 MFMA 32x32x2 implicit GEMM family)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA, 4),
-                "measured_on": ("the timed schedule (CodecPipeline: encoder || decoder), second pass of the same K steps with every conv launch of both "
+                "measured_on": ("the timed schedule (CodecPipeline), second pass of the same K steps with every conv launch of all its codec "
                                 "objects bracketed by HIP events on its own stream: FLOPs / time during which >= 1 conv kernel runs") if insitu else
                                "one step, launch by launch (serial schedule): sum 2MNK / sum of HIP-event launch durations",
                 "in_schedule": insitu,
@@ -368,10 +377,11 @@ def main():
                                "synthetic seeded weights (canonical ChannelProgresssiveWACNN)",
                    "images_per_gpu": B, "height": S, "width": S, "quality": q, "sharding": f"images x {world} ranks",
                    "step_schedule": ("progressivecodec_amd.CodecPipeline.code(): every step = compress() + decompress() of the batch, all inside the timed "
-                                     "region; the decode of step i overlaps the encode of step i+1 (the library's encoder and decoder objects, two "
-                                     "streams, decoder host thread)")
+                                     f"region; {args.pairs} encoder / decoder pair(s) of the library's objects, each with its own streams and host "
+                                     "threads: a pair decodes step i beside the encode of its next step, and the pairs take the steps in turn")
                    if args.overlap else "every step = compress() then decompress(), strictly one after the other, on one model object",
-                   "api": "CodecPipeline.code" if args.overlap else "ChannelProgresssiveWACNN.compress / .decompress",
+                   "api": f"CodecPipeline(n_pairs={args.pairs}).code" if args.overlap else "ChannelProgresssiveWACNN.compress / .decompress",
+                   "encoder_decoder_pairs": args.pairs if args.overlap else 0,
                    "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)")},
         "sequential_value": round(seq_value, 3) if seq_value else (None if args.overlap else round(value, 3)),
         "sequential_note": "the same steps strictly one after the other on one codec object (--overlap 0 schedule): what a drop-in "
@@ -395,7 +405,7 @@ def main():
         used_gib = float(t.item())
     nt_, first_, allowed_ = C.c_int(), C.c_int(), C.c_int()
     lib().pc_host_pool_plan(C.byref(nt_), C.byref(first_), C.byref(allowed_))
-    line["per_rank_resources"] = {"codec_objects": 2 if pipe is not None else 1, "weights_bytes_per_object": int(sum(v.numel() * 4 for k, v in sd.items()
+    line["per_rank_resources"] = {"codec_objects": 2 * args.pairs if pipe is not None else 1, "weights_bytes_per_object": int(sum(v.numel() * 4 for k, v in sd.items()
                                                                                                           if hasattr(v, "numel") and v.dtype == torch.float32)),
                                   "hbm_in_use_gib_max_over_ranks": round(used_gib, 2), "hbm_total_gib": round(total_b / 2.0 ** 30, 1),
                                   "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES", "default (4)"),

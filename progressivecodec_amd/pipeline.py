@@ -61,9 +61,15 @@ class CodecPipeline:
     ``qualities`` (a list: the shared-base multi-level path), optional ``mask_pol``) yielding ``(job, enc, dec)`` in job order --
     ``enc`` / ``dec`` are what ``compress`` / ``decompress`` (or ``compress_levels`` / ``decompress_levels``) return.  The encoder runs at
     most ``queue_depth`` items ahead of the decoder.  Results are safe to use on the caller's current stream when they are yielded.
+
+    ``n_pairs`` > 1 (round 4): that many encoder / decoder PAIRS, each with its own objects, streams, encoder thread and decoder thread;
+    jobs are handed to whichever pair is free and the results come back in job order.  One pair keeps about 2.4 convolution kernels in
+    flight, which leaves the MFMA pipes idle ~30 % of the time; a second pair fills part of that: 47.2 -> 49.7
+    MP/s on Config 2, 50.5 with three (tools/multi_pipeline_probe.py, profiles/r04_m_*).  Every pair is another two weights copies
+    (1.2 GB) plus its workspaces (3 GB at Config 2, 48 GB at Config 4's shard): the default stays 1; bench.py uses 2.
     """
 
-    def __init__(self, state_dict=None, device="cuda:0", queue_depth=2, _encoder=None, **model_kwargs):
+    def __init__(self, state_dict=None, device="cuda:0", queue_depth=2, _encoder=None, n_pairs=1, **model_kwargs):
         import torch
         from .model import ChannelProgresssiveWACNN
         self.hw_queues_ok = request_hw_queues()
@@ -86,22 +92,35 @@ class CodecPipeline:
             self.enc = ChannelProgresssiveWACNN(device=device, **model_kwargs)
             self.enc.load_state_dict(state_dict)
             self.enc.update()
-        self.dec = ChannelProgresssiveWACNN(device=device, **model_kwargs)
-        self.dec.load_state_dict(state_dict)          # carries the encoder's CDF tables and scale table when it has them
-        self.dec.update()
+        def another():
+            net = ChannelProgresssiveWACNN(device=device, **model_kwargs)
+            net.load_state_dict(state_dict)           # carries the encoder's CDF tables and scale table when it has them
+            net.update()
+            return net
+        self.dec = another()
         self.device = self.enc.device
         self.queue_depth = max(1, int(queue_depth))
         self.s_enc = torch.cuda.Stream(self.device)
         self.s_dec = torch.cuda.Stream(self.device)
+        self.n_pairs = max(1, int(n_pairs))
+        #: (encoder, decoder, encode stream, decode stream) per pair; pair 0 is self.enc / self.dec
+        self.pairs = [(self.enc, self.dec, self.s_enc, self.s_dec)]
+        for _ in range(self.n_pairs - 1):
+            self.pairs.append((another(), another(), torch.cuda.Stream(self.device), torch.cuda.Stream(self.device)))
         self._busy = threading.Lock()
 
+    @property
+    def objects(self):
+        """every codec object of the pipeline (encoders and decoders of all pairs)"""
+        return [o for p in self.pairs for o in p[:2]]
+
     @classmethod
-    def from_model(cls, model, queue_depth=2):
+    def from_model(cls, model, queue_depth=2, n_pairs=1):
         """`model`: a loaded and updated ChannelProgresssiveWACNN -- it becomes the encoder; the decoder is a second object with the same
         state dict (another 608 MB of HBM)."""
         if model._gc is None or model._eb is None:
             raise ValueError("Uninitialized CDFs. Run update() first")
-        return cls(_encoder=model, queue_depth=queue_depth)
+        return cls(_encoder=model, queue_depth=queue_depth, n_pairs=n_pairs)
 
     # ------------------------------------------------------------------ one item on one object
     @staticmethod
@@ -129,6 +148,9 @@ class CodecPipeline:
         """Generator: (job, enc, dec) per job, in order; the decode of job i runs beside the encode of job i+1.  `on_encoded(job, enc)`
         (optional) is called on the caller's thread right after a job's compress returned, before its decode is queued."""
         import torch
+        if self.n_pairs > 1:
+            yield from self._code_pairs(jobs, on_encoded)
+            return
         if not self._busy.acquire(blocking=False):
             raise PipelineError("this CodecPipeline is already running a code() loop (one schedule per pipeline object)")
         q_in = queue.Queue(maxsize=self.queue_depth)
@@ -232,6 +254,134 @@ class CodecPipeline:
             if th.is_alive():
                 raise PipelineError("decoder thread did not finish")
 
+    def _code_pairs(self, jobs, on_encoded=None):
+        """code() with n_pairs > 1: every pair runs the single-pair schedule -- its encoder thread takes the next job of the stream, encodes
+        it and queues it for the pair's decoder thread -- and the caller's generator hands the results out in job order.  The jobs
+        iterator is advanced under a lock by whichever encoder thread is free (so a lazily built job, e.g. the harness's padding, is
+        prepared on the stream that will consume it); at most n_pairs * (queue_depth + 1) jobs are taken beyond the last one handed out.
+        `on_encoded` runs on the encoder threads."""
+        import torch
+        if not self._busy.acquire(blocking=False):
+            raise PipelineError("this CodecPipeline is already running a code() loop (one schedule per pipeline object)")
+        it = iter(jobs)
+        cv = threading.Condition()
+        st = {"next": 0, "out": 0, "done": False, "err": None, "stop": False}
+        results = {}
+        window = self.n_pairs * (self.queue_depth + 1)
+        dev = self.device
+        caller = torch.cuda.current_stream(dev)
+        queues = [queue.Queue(maxsize=self.queue_depth) for _ in self.pairs]
+
+        def fail(e):
+            with cv:
+                if st["err"] is None:
+                    st["err"] = e
+                st["stop"] = True
+                cv.notify_all()
+
+        def take():
+            with cv:
+                while not st["stop"] and not st["done"] and st["next"] - st["out"] >= window:
+                    cv.wait(timeout=1.0)
+                if st["stop"] or st["done"]:
+                    return None
+                try:
+                    job = next(it)
+                except StopIteration:
+                    st["done"] = True
+                    cv.notify_all()
+                    return None
+                seq = st["next"]
+                st["next"] += 1
+                return seq, job
+
+        def encoder(r):
+            enc_net, _, s_enc, _ = self.pairs[r]
+            try:
+                torch.cuda.set_device(dev)
+                s_enc.wait_stream(caller)
+                with torch.cuda.stream(s_enc):
+                    while True:
+                        t = take()
+                        if t is None:
+                            break
+                        seq, job = t
+                        enc = self._encode(enc_net, job)
+                        if on_encoded is not None:
+                            on_encoded(job, enc)
+                        queues[r].put((seq, job, enc))
+            except BaseException as e:
+                fail(e)
+            finally:
+                queues[r].put(None)
+
+        def decoder(r):
+            _, dec_net, _, s_dec = self.pairs[r]
+            try:
+                torch.cuda.set_device(dev)
+                with torch.cuda.stream(s_dec):
+                    while True:
+                        item = queues[r].get()
+                        if item is None:
+                            return
+                        if st["stop"]:
+                            continue                       # drain: the producer must never block on a dead consumer
+                        seq, job, enc = item
+                        e0 = None
+                        if job.get("time_decode"):
+                            e0 = torch.cuda.Event(enable_timing=True)
+                            e0.record(s_dec)
+                        dec = self._decode(dec_net, job, enc)
+                        ev = torch.cuda.Event(enable_timing=e0 is not None)
+                        ev.record(s_dec)
+                        if e0 is not None:
+                            job["_dec_events"] = (e0, ev)
+                        with cv:
+                            results[seq] = (job, enc, dec, ev)
+                            cv.notify_all()
+            except BaseException as e:
+                fail(e)
+                while queues[r].get() is not None:
+                    pass
+
+        threads = [threading.Thread(target=encoder, args=(r,), name=f"pcodec-encoder-{r}", daemon=True) for r in range(self.n_pairs)] + \
+                  [threading.Thread(target=decoder, args=(r,), name=f"pcodec-decoder-{r}", daemon=True) for r in range(self.n_pairs)]
+        for t in threads:
+            t.start()
+        try:
+            while True:
+                with cv:
+                    while st["out"] not in results and st["err"] is None and not (st["done"] and st["out"] >= st["next"]):
+                        if not cv.wait(timeout=600):
+                            raise PipelineError("the pipeline made no progress for 600 s")
+                    if st["err"] is not None:
+                        raise st["err"]
+                    if st["out"] not in results:
+                        break                              # every job taken has been handed out and the stream is exhausted
+                    job, enc, dec, ev = results.pop(st["out"])
+                    st["out"] += 1
+                    cv.notify_all()
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                for d in (dec if isinstance(dec, (list, tuple)) else [dec]):
+                    d["x_hat"].record_stream(cur)
+                for e in (enc if isinstance(enc, (list, tuple)) else [enc]):
+                    for m in e.get("masks", []):
+                        m.record_stream(cur)
+                yield job, enc, dec
+        finally:
+            with cv:
+                st["stop"] = True
+                cv.notify_all()
+            for t in threads:
+                t.join(timeout=600)
+            for _, _, s_e, s_d in self.pairs:
+                caller.wait_stream(s_e)
+                caller.wait_stream(s_d)
+            self._busy.release()
+            if any(t.is_alive() for t in threads):
+                raise PipelineError("a pipeline thread did not finish")
+
     @staticmethod
     def decode_ms(job):
         """Milliseconds the decode stream spent on a job that was submitted with ``"time_decode": True`` (from the end of the item before
@@ -257,7 +407,7 @@ class CodecPipeline:
         from ._lib import check, lib
         L = lib()
         check(L.pc_profile_set_epoch(self.device.index or 0), "pc_profile_set_epoch")
-        for net in (self.enc, self.dec):
+        for net in self.objects:
             net.set_option("profile_in_schedule", 1)
             check(L.pc_codec_profile_begin(net._h), "pc_codec_profile_begin")
         try:
@@ -266,7 +416,7 @@ class CodecPipeline:
         finally:
             iv = []
             tot_fl = tot_by = 0.0
-            for net in (self.enc, self.dec):
+            for net in self.objects:
                 nl, ms, fl, by = C.c_int64(), C.c_double(), C.c_double(), C.c_double()
                 check(L.pc_codec_profile_end(net._h, C.byref(nl), C.byref(ms), C.byref(fl)), "pc_codec_profile_end")
                 check(L.pc_codec_profile_bytes(net._h, C.byref(by)), "pc_codec_profile_bytes")

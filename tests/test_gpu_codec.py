@@ -1214,6 +1214,17 @@ def test_codec_pipeline_equals_sequential_calls():
     with pytest.raises(NotImplementedError):
         pipe.run(bad)
     check(pipe.run(jobs))
+    # two encoder / decoder pairs: jobs handed to whichever pair is free, results still in job order and identical
+    pipe3 = CodecPipeline(synth_sd(), device="cuda:0", n_pairs=2)
+    assert len(pipe3.objects) == 4 and len({o._h.value for o in pipe3.objects}) == 4
+    check(pipe3.run(jobs))
+    check(pipe3.run(jobs * 1))
+    with pytest.raises(NotImplementedError):
+        pipe3.run(bad)
+    check(pipe3.run(jobs))
+    pr2 = pipe3.profile_conv_in_schedule(jobs)
+    assert pr2["jobs"] == len(jobs) and pr2["launches"] > 500
+    del pipe3
     # in-schedule profile: brackets only, same results, intervals on one timeline
     pr = pipe.profile_conv_in_schedule(jobs)
     assert pr["jobs"] == len(jobs) and pr["launches"] > 500 and 0 < pr["busy_ms"] <= pr["window_ms"] * 1.001 and pr["sum_ms"] >= pr["busy_ms"] * 0.999
