@@ -75,6 +75,8 @@ struct pc_codec {
     bool finalized = false;
     std::atomic<bool> busy{false};               // a compress / decompress / forward call is inside: the object is not re-entrant
     hipEvent_t call_done = nullptr;              // recorded on the caller's stream when a call returns; the next call's stream waits for it
+    hipEvent_t staging_done = nullptr;           // decoder: recorded behind the last chain of a decompress -- every H2D copy out of the pinned staging has run by then
+    bool staging_pending = false;
     pc_rowtab_cache* rowtabs = nullptr;          // per-geometry row tables of the conv kernel: owned here, freed in pc_codec_destroy
     std::map<std::string, HostTensor> sd;
     std::vector<void*> weight_allocs;
@@ -857,6 +859,7 @@ extern "C" void pc_codec_destroy(pc_codec* c)
     for (auto& L : c->lanes) { (void)hipStreamDestroy(L.sA); (void)hipStreamDestroy(L.sB); (void)hipEventDestroy(L.eA); (void)hipEventDestroy(L.eB); (void)hipEventDestroy(L.eDone); }
     if (c->eFork) (void)hipEventDestroy(c->eFork);
     if (c->call_done) (void)hipEventDestroy(c->call_done);
+    if (c->staging_done) (void)hipEventDestroy(c->staging_done);
     for (hipEvent_t e : c->lvl_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->slice_ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->pipe_ev) (void)hipEventDestroy(e);
@@ -2018,6 +2021,17 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
     k.cust_map = c->cust_map; c->cust_map = nullptr;
     k.rem_ckpt = c->rem_ckpt; c->rem_ckpt = nullptr;
     const size_t per = (size_t)SLICE * HW, per_z = (size_t)NCH * ZHW;
+    // decompress() returns with work still in flight -- x_hat, and the chains' LAST host-to-device symbol copies, which read the pinned
+    // staging asynchronously.  The host is about to write that staging again (the z symbols below, then every slice's) and may re-allocate it:
+    // wait until the previous call's chains have run (an event behind its last chain, not behind its synthesis transform).  Round 4: found by
+    // the CodecPipeline test under the env matrix -- the next call's z decode overwrote lane 0's pending symbols of the last slice, 1 run in 8.
+    if (c->staging_pending) { HIPCHK(hipEventSynchronize(c->staging_done)); c->staging_pending = false; }
+    if (!c->staging_done) HIPCHK(hipEventCreateWithFlags(&c->staging_done, hipEventDisableTiming));
+    struct StagingMark {                         // recorded behind every chain section (`st` has joined the lanes / the second chain stream by then), i.e. in
+        pc_codec* c; hipStream_t st; bool marked; // front of the synthesis transforms, whose tail the next call's host work may overlap; and, on whatever
+        void mark() { if (hipEventRecord(c->staging_done, st) == hipSuccess) { c->staging_pending = true; marked = true; } }   // path the call leaves by, at the exit
+        ~StagingMark() { if (!marked) mark(); }
+    } staging_mark{c, st, false};
     PCCHK(ensure_host_staging(c, std::max(per * B, per_z * B)));
     const int nt = c->n_threads == 1 ? 1 : 0;
 
@@ -2066,6 +2080,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
         k.step0 = 0; k.step1 = NS0; k.enh = false; k.mode = 0;
         PCCHK(run_chain(k, st, true, y_strings, y_lens));                                // :874-904
     }
+    staging_mark.mark();
     const size_t img_elems = (size_t)B * 3 * (16 * h) * (16 * w);
     // Two levels in flight (round 4): the enhancement chains of the levels that are still to decode are independent of each other, and a
     // chain alone leaves the GPU idle through every slice's host entropy decode (at 4K: 93 of 148 ms).  They are decoded in PAIRS -- one
@@ -2105,6 +2120,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
             } else {
                 PCCHK(decode_lane(ka, 0, B, st, st, nullptr, nullptr, "PA", y_strings, y_lens, nt));
             }
+            staging_mark.mark();
             PCCHK(g_s(c, st, c->gs[1], ka.ye, B, h, w, x_hat + (size_t)la * img_elems));
             if (lb >= 0) PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, x_hat + (size_t)lb * img_elems));
         }
@@ -2120,6 +2136,7 @@ int decompress_impl(pc_codec* c, const uint8_t* const* y_strings, const size_t* 
             k.mode = mask_mode_for(k.cust_map ? PC_MASK_POINT_BASED_STD : mask_pol, qualities[l], &k.q);
             k.quality = qualities[l]; k.mask_pol = mask_pol;
             PCCHK(run_chain(k, st, true, y_strings, y_lens));                            // :930-983
+            staging_mark.mark();
         }
         PCCHK(g_s(c, st, c->gs[1], k.ye, B, h, w, out));                                 // :986-990
     }

@@ -11,8 +11,10 @@ ONLY=${1:-}
 run() {
   if [ -n "$ONLY" ] && ! echo "$*" | grep -qE "$ONLY"; then return; fi
   echo "== $*"
-  env "$@" timeout -k 10 400 python -m pytest tests -x -q -m gpu -k "not config4 and not config5 and not 4k_frame and not large_tiles" 2>&1 | tail -1
-  [ ${PIPESTATUS[0]} -eq 0 ] || fail=1
+  env "$@" timeout -k 10 400 python -m pytest tests -x -q -m gpu -k "not config4 and not config5 and not 4k_frame and not large_tiles" > /tmp/env_matrix_one.log 2>&1
+  rc=$?
+  tail -1 /tmp/env_matrix_one.log
+  if [ $rc -ne 0 ]; then fail=1; grep -nE "^E |^(FAILED|ERROR)|Error" /tmp/env_matrix_one.log | head -40; fi
 }
 run PC_CONV_POLICY=0
 run PC_CONV_POLICY=1
