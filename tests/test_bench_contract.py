@@ -47,6 +47,19 @@ def test_bench_line_contract():
                   "host_decode_ms_in_decompress_summed_over_chains", "symbols_per_stream"):
             assert k in rn[cfg], (cfg, k)
     assert rn["config5_frame"]["symbols_per_stream"] == 32 * 136 * 240
+    # round 4: the schedule is the library's, the roofline is measured in it, the parity figure carries the root flips
+    assert j["config"]["api"].startswith("CodecPipeline") and j["config"]["encoder_decoder_pairs"] >= 1
+    ins = r["in_schedule"]
+    assert ins and abs(ins["achieved"] - r["achieved"]) < 1e-6 and 0.5 < ins["conv_busy_frac_of_window"] <= 1.0 and ins["mean_conv_kernels_in_flight"] >= 1.0
+    assert ins["steps"] == j["steps"] and ins["instrumented_ms_per_step"] >= 0.9 * ins["uninstrumented_ms_per_step"]
+    lbl = r["launch_by_launch"]
+    assert 0 < lbl["achieved"] <= r["achieved"] * 1.05 and abs(lbl["frac"] - lbl["achieved"] / r["peak"]) < 1e-3
+    assert j["per_rank_resources"]["codec_objects"] == 2 * j["config"]["encoder_decoder_pairs"] and j["per_rank_resources"]["hbm_in_use_gib_max_over_ranks"] > 1
+    rf = rp["root_flips"]
+    assert rf["source"] and (rf["symbols"], rf["indexes"]) == (rf["expected_by_fixture"]["symbols"], rf["expected_by_fixture"]["indexes"]) and rf["rate_per_coded_symbol"] < 2e-5
+    assert "abs_psnr_diff_db_histogram_flipped_images" in rp and int(rp["images_within_1e-4_db"].split("/")[0]) >= 28
+    pg = c["port_strings_identical_to_reference_golden"]
+    assert pg is None or {"z", "y", "images_identical"} <= set(pg)
 
 
 def test_committed_profiles_belong_to_this_build():
