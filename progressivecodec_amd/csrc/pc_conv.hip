@@ -44,6 +44,7 @@
 #include "pc_device.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -389,17 +390,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const pc_conv_params p)
 // ([channel][pixel]) -- exactly the A image phase 2 needs; phase 2 contracts x^2 with gamma (K = 192, gamma chunks double-buffered
 // through LDS) and the epilogue reads x back from the same image: out = x * rsqrt(beta + norm).  Per output element the two fmaf
 // chains, the bias adds, the square and the rsqrt are those of the two-launch form (same k order, same operations): bit-identical.
-// LDS: 192 x 65 floats of x + 2 x 16 x 196 of weights = 75 008 B -> two workgroups per CU.
+// Phase 2 reads its operands the unified kernel's way: 16-byte k-quads ([pixel][channel] image of x, gamma chunks as [column][k-quad] with
+// an XOR swizzle), one ds_read_b128 per operand and four MFMA steps.  LDS: 64 x 196 floats of x + 2 x 192 x 16 of weights = 75 392 B
+// -> two workgroups per CU.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_params p)
 {
     constexpr int BM = 64, CN = 192, BK = 16, TN = 3;
-    constexpr int LDX = BM + 1, LDA = BM + 4, LDB = CN + 4;
+    constexpr int XP = CN + 4, LDA = BM + 4, LDB = CN + 4;
     extern __shared__ float fsm[];
-    float* Xs = fsm;                                   // [CN][LDX]
-    float* Bs = Xs + CN * LDX;                         // phase 2: 2 x [BK][LDB]; phase 1: [BK][LDB] weights, then [BK][LDA] pixels
+    // x image [pixel][channel], pitch 196 floats: phase 1 writes it conflict-free (lane = channel), phase 2 reads 16-byte k-quads of a
+    // pixel row (consecutive rows start 16 B apart modulo 128: eight lanes, eight bank quads), the epilogue reads it as it was written
+    float* Xs = fsm;                                   // [BM][XP]
+    // phase 2: 2 x [CN][BK] gamma chunks as 16-byte k-quads, quad q of column n stored at quad slot q ^ ((n >> 1) & 3) (conflict-free
+    // ds_write_b128 / ds_read_b128); phase 1: [BK][LDB] weights, then [BK][LDA] pixels, k-major (conv_igemm_kernel's image)
+    float* Bs = Xs + BM * XP;
     float* As = Bs + BK * LDB;
-    int* ktab = reinterpret_cast<int*>(Bs + 2 * BK * LDB);   // [2][80]: per flattened k = tap * Cin + c, the element offset from the pixel's (iy0, ix0) and dy << 16 | dx
+    static_assert(BK * LDB + BK * LDA <= 2 * CN * BK, "phase 1 fits phase 2's buffers");
+    int* ktab = reinterpret_cast<int*>(Bs + 2 * CN * BK);    // [2][80]: per flattened k = tap * Cin + c, the element offset from the pixel's (iy0, ix0) and dy << 16 | dx
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -502,7 +510,7 @@ __global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_pa
             const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[j][r];
             if (p.bias) v = v + bv;
-            Xs[n * LDX + row] = v;
+            Xs[row * XP + n] = v;
             acc[j][r] = 0.0f;
         }
     }
@@ -515,14 +523,9 @@ __global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_pa
         for (int i = 0; i < 3; ++i) rb[i] = *reinterpret_cast<const float4*>(p.fg_gamma + (int64_t)g_n[i] * CN + chunk * BK + g_q[i] * 4);
     };
     auto store2 = [&](int buf) {
-        float* b = Bs + buf * BK * LDB;
+        float* b = Bs + buf * CN * BK;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            b[(g_q[i] * 4 + 0) * LDB + g_n[i]] = rb[i].x;
-            b[(g_q[i] * 4 + 1) * LDB + g_n[i]] = rb[i].y;
-            b[(g_q[i] * 4 + 2) * LDB + g_n[i]] = rb[i].z;
-            b[(g_q[i] * 4 + 3) * LDB + g_n[i]] = rb[i].w;
-        }
+        for (int i = 0; i < 3; ++i) *reinterpret_cast<float4*>(b + g_n[i] * BK + ((g_q[i] ^ ((g_n[i] >> 1) & 3)) << 2)) = rb[i];
     };
     load2(0);
     store2(0);
@@ -531,15 +534,26 @@ __global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_pa
     for (int chunk = 0; chunk < NCH2; ++chunk) {
         const int cur = chunk & 1;
         if (chunk + 1 < NCH2) load2(chunk + 1);
-        const float* a = Xs + (chunk * BK) * LDX + wm * 32 + l31;
-        const float* b = Bs + cur * BK * LDB + wn * (TN * 32) + l31;
+        // operands as 16-byte k-quads, the unified kernel's way: lanes 0-31 hold quad 2g, lanes 32-63 quad 2g+1 of an aligned group of 8 k --
+        // MFMA step s then contracts k = 8g + s and 8g + 4 + s, the contract's 0,4,1,5,2,6,3,7.  One read per operand feeds four MFMAs
+        // (the first form read 32 bits per MFMA step: 32 reads + 8 multiplies per chunk against 8 + 4 packed here; at two waves per SIMD
+        // every instruction between MFMAs shows)
+        const float* arow = Xs + (wm * 32 + l31) * XP + chunk * BK;
+        const float* bbase = Bs + cur * CN * BK;
 #pragma unroll
-        for (int st = 0; st < BK / 2; ++st) {
-            const int kk = (st >> 2) * 8 + (st & 3) + 4 * half;
-            float av = a[kk * LDX];
-            av = av * av;                                                 // gdn.py:56: the contraction runs over x^2
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            f32x4 a4 = *reinterpret_cast<const f32x4*>(arow + 8 * g8 + 4 * half);
+            a4 = a4 * a4;                                                 // gdn.py:56: the contraction runs over x^2
+            f32x4 b4[TN];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk * LDB + j * 32], acc[j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * (TN * 32) + j * 32 + l31;
+                b4[j] = *reinterpret_cast<const f32x4*>(bbase + col * BK + (((2 * g8 + half) ^ ((col >> 1) & 3)) << 2));
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[st], b4[j][st], acc[j], 0, 0, 0);
         }
         if (chunk + 1 < NCH2) store2(cur ^ 1);
         __syncthreads();
@@ -555,7 +569,7 @@ __global__ __launch_bounds__(256) void conv_igemm_in_gdn_kernel(const pc_conv_pa
             const int64_t m = m0 + row;
             if (m >= (int64_t)p.M) continue;
             const float v = acc[j][r] + bv;
-            p.out[m * p.out_sx + n] = Xs[n * LDX + row] * pc_rsqrtf(v);
+            p.out[m * p.out_sx + n] = Xs[row * XP + n] * pc_rsqrtf(v);
         }
     }
 }
@@ -1701,7 +1715,7 @@ int pc_conv_launch(const pc_conv_params& p_in, hipStream_t stream)
         if (!p.smallc || p.wlayout != 0 || p.Cout != 192 || p.nphase != 1 || !p.dense_out || p.out_sc != 1 || !p.fg_beta || p.epi != PC_EPI_NONE ||
             p.ngroup == 2 || p.ntap[0] * p.Cin > 80)
             return PC_ERR_ARG;
-        constexpr size_t lds = (size_t)(192 * 65 + 2 * 16 * 196 + 2 * 80) * sizeof(float);
+        constexpr size_t lds = (size_t)(64 * 196 + 2 * 192 * 16 + 2 * 80) * sizeof(float);
         if ((int64_t)3 * p.H * p.W >= ((int64_t)1 << 31)) return PC_ERR_ARG;             // (element offsets inside one image are 32-bit)
         static std::atomic<uint32_t> attr_set{0};
         int dev = 0;
