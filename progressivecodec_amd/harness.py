@@ -84,7 +84,7 @@ def _pipeline_of(model):
 
 
 def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", device="cuda", shared_base=False, batch_same_size=False,
-                     overlap=False, group_size=6):
+                     overlap=False, group_size=18):
     """images: iterable of [1,3,H,W] (or [3,H,W]) float tensors in [0,1].
     Returns (bpp[level], psnr[level], dec_time[level]) averaged over the images, as step.py:404 does,
     plus the per-image table.
@@ -99,7 +99,8 @@ def compress_with_ac(model, images, pr_list=None, mask_pol="point-based-std", de
     identical; dec_time is then the time of the joint decode divided by the number of levels.
 
     overlap=True (implies batch_same_size and shared_base): the groups of equal-sized images are cut into jobs of at most `group_size`
-    images and run through a CodecPipeline (progressivecodec_amd/pipeline.py) -- the decode of job i beside the encode of job i+1, on
+    images (default 18: with two levels in flight inside every multi-level call -- round 4 -- large jobs are the efficient ones; the
+    overlap then hides one job's decode behind the next job's encode) and run through a CodecPipeline (progressivecodec_amd/pipeline.py) -- the decode of job i beside the encode of job i+1, on
     an encoder and a decoder object, two streams, two host threads.  `model` may be a CodecPipeline, or a loaded model around which
     one is built on first use.  Same strings, same x_hat, same RD table; dec_time = the decode stream's time on the job / (images * levels)."""
     import torch
