@@ -1070,6 +1070,24 @@ def test_config3_kodak_sized_set_all_13_levels():
             print(f"Config 3 image {i} ({gi['H']}x{gi['W']}) q={q}: first diverging slice {cmp_['first_diverging_slice'][0]}, bpp {b_here:.6f} (ref {lv['bpp']:.6f}), "
                   f"psnr {p_here:.6f} (ref {lv['psnr']:.6f})")
     print(f"Config 3: {n_ff}/26 (image, level) pairs flip-free against the reference; RD table (24 images) bpp {[round(v, 4) for v in bpp]} psnr {[round(v, 4) for v in psnr]}")
+    # Root flips (round 4, tests/golden/config3_roots.npz from make_golden_config3_roots.py): every pair above diverges in a BASE slice, the same
+    # for all 13 levels of an image, so the rounding flips that separate the contract from the reference on Config 3 are, per image, the
+    # differing elements of that one slice -- counted against the reference's own symbol / index planes; the GPU must reproduce the counts of
+    # the contract oracle the fixture was made with, and the rate per coded symbol must stay at the Config-2 level.
+    rp = os.path.join(os.path.dirname(__file__), "golden", "config3_roots.npz")
+    if os.path.exists(rp):
+        R = np.load(rp)
+        for n, (i, sl) in enumerate(zip(R["image"].tolist(), R["slice"].tolist())):
+            x = imgs[i]
+            per = 32 * (x.shape[2] // 16) * (x.shape[3] // 16)
+            net.compress(x.cuda(), 0.0, "point-based-std")
+            gsym = net.read_tap("sym", np.int32)[: 10 * per].reshape(10, per)
+            gidx = net.read_tap("idx", np.int32)[: 10 * per].reshape(10, per)
+            ds, di = int((gsym[sl] != R["sym"][n]).sum()), int((gidx[sl] != R["idx"][n]).sum())
+            print(f"Config 3 image {i}: root slice {sl} ({per} elements): {ds} symbol and {di} index flips against the reference "
+                  f"(fixture: {int(R['contract_sym_flips'][n])} / {int(R['contract_idx_flips'][n])}); {(ds + di) / (10.0 * per):.2e} per coded base symbol")
+            assert (ds, di) == (int(R["contract_sym_flips"][n]), int(R["contract_idx_flips"][n]))
+            assert (ds + di) / (10.0 * per) <= 5e-5
     # (at Kodak size an (image, level) pair is ~1 M coded symbols: with float-rounding flips at ~1e-5 per symbol a flip-free pair is the
     #  exception -- the count is reported, the tolerances above hold for every pair)
 
